@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""offline pipeline-split explorer (reference: debug.py).
+
+Thin entrypoint kept under the reference's file name; the implementation is `ddl.cli.main_split_explorer`.
+Run: `python debug.py [--flags]`, or under `torchrun` / the torchx-style component for multi-GPU.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from ddl.cli import main_split_explorer  # noqa: E402
+
+if __name__ == "__main__":
+    main_split_explorer()

@@ -1,0 +1,318 @@
+"""Process-group layer: init/teardown, the 2-D (dp x pp) mesh, collective wrappers.
+
+Reference (ddp.py:28-35, pp.py:27-34, ddp_n_pp.py:30-41, communication_time.py:7-14):
+``init_process_group('nccl')`` hard-coded, ``local_rank = rank % device_count``, and
+``init_device_mesh('cuda', (3, 2), ('dp', 'pp'))`` for the hybrid.
+
+Here:
+  * backend ``"nccl"`` on ROCm *is* RCCL over xGMI; ``gloo`` is the CPU test transport
+    with the same wrapper API - not a second production backend.
+  * ``Mesh2D`` builds the sub-communicators itself, parametric in (dp, pp), row-major
+    like the reference (``rank = dp_idx * pp + pp_idx``): a pipeline's stages are
+    adjacent ranks (neighbouring GPUs - every MI355X pair is one xGMI hop), a DP group
+    is the same stage across pipelines.
+  * wrappers pick flat ``*_into_tensor`` collectives (one RCCL call on a contiguous
+    arena range instead of list-of-tensor forms) and emulate what gloo lacks
+    (reduce-scatter, AVG) so multi-process logic is testable on CPU.
+  * ``CollectiveChecker`` is the race/ordering tool the reference never had
+    (SURVEY 5.2): every wrapper call appends (op, numel, dtype, group) to a per-step
+    log whose hash is all-gathered and compared on demand.
+"""
+from __future__ import annotations
+
+import datetime
+import hashlib
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass
+class CommContext:
+    rank: int
+    world_size: int
+    local_rank: int
+    device: torch.device
+    backend: str
+
+    @property
+    def is_distributed(self) -> bool:
+        return self.world_size > 1 or dist.is_initialized()
+
+
+_CHECKER: Optional["CollectiveChecker"] = None
+
+
+def env_rank() -> int:
+    return int(os.environ.get("RANK", "0"))
+
+
+def env_world_size() -> int:
+    return int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def pick_device(local_rank: int, want: str = "auto") -> torch.device:
+    if want == "cpu" or (want == "auto" and not torch.cuda.is_available()):
+        return torch.device("cpu")
+    return torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
+
+
+def init(backend: str = "auto", device: str = "auto", timeout_s: int = 600,
+         force: bool = False) -> CommContext:
+    """env:// rendezvous (torchrun / torchx export RANK, WORLD_SIZE, MASTER_*).
+
+    With WORLD_SIZE unset (plain ``python script.py``) no process group is created
+    unless ``force`` - ``single.py`` never needs one.
+    """
+    rank, world = env_rank(), env_world_size()
+    # the reference derives local_rank = rank % device_count (ddp.py:30); prefer the launcher's value
+    local_rank = int(os.environ.get("LOCAL_RANK", rank % max(torch.cuda.device_count(), 1)
+                                    if torch.cuda.is_available() else 0))
+    dev = pick_device(local_rank, device)
+    if backend == "auto":
+        backend = "nccl" if dev.type == "cuda" else "gloo"
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)
+    if (world > 1 or force or "RANK" in os.environ) and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = dev   # eager RCCL communicator creation, binds the PG to this GPU
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=timeout_s), **kw)
+    return CommContext(rank, world, local_rank, dev, backend)
+
+
+def destroy() -> None:
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def is_dist() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_rank(group=None) -> int:
+    return dist.get_rank(group) if is_dist() else 0
+
+
+def get_world_size(group=None) -> int:
+    return dist.get_world_size(group) if is_dist() else 1
+
+
+def backend_of(group=None) -> str:
+    return dist.get_backend(group) if is_dist() else "none"
+
+
+# --------------------------------------------------------------------------------------
+# 2-D mesh
+# --------------------------------------------------------------------------------------
+class Mesh2D:
+    """(dp, pp) process mesh, row-major: ``rank = dp_idx * pp_size + pp_idx``.
+
+    Replaces ``init_device_mesh('cuda', (3,2), ('dp','pp'))`` (ddp_n_pp.py:32-33).
+    Every rank creates every sub-group in the same order (a c10d requirement).
+    """
+
+    def __init__(self, dp_size: int, pp_size: int) -> None:
+        world, rank = get_world_size(), get_rank()
+        if dp_size * pp_size != world:
+            raise ValueError(f"mesh {dp_size}x{pp_size} does not cover world size {world}")
+        self.dp_size, self.pp_size = dp_size, pp_size
+        self.rank = rank
+        self.dp_index, self.pp_index = divmod(rank, pp_size)
+        self.mesh = [[d * pp_size + p for p in range(pp_size)] for d in range(dp_size)]
+        self._pp_group = None
+        self._dp_group = None
+        if is_dist():
+            for d in range(dp_size):                       # pp groups: rows
+                ranks = self.mesh[d]
+                g = dist.new_group(ranks) if pp_size > 1 else None
+                if d == self.dp_index:
+                    self._pp_group, self.pp_ranks = g, ranks
+            for p in range(pp_size):                       # dp groups: columns
+                ranks = [self.mesh[d][p] for d in range(dp_size)]
+                g = dist.new_group(ranks) if dp_size > 1 else None
+                if p == self.pp_index:
+                    self._dp_group, self.dp_ranks = g, ranks
+        else:
+            self.pp_ranks, self.dp_ranks = [0], [0]
+
+    def get_group(self, name: str):
+        if name == "dp":
+            return self._dp_group
+        if name == "pp":
+            return self._pp_group
+        raise KeyError(name)
+
+    def size(self, name: str) -> int:
+        return self.dp_size if name == "dp" else self.pp_size
+
+    def coord(self, name: str) -> int:
+        return self.dp_index if name == "dp" else self.pp_index
+
+    @property
+    def last_stage_rank_of_first_pipeline(self) -> int:
+        """Global rank that owns the logging role: mesh[0][-1] (ddp_n_pp.py:275)."""
+        return self.mesh[0][-1]
+
+    def __repr__(self) -> str:
+        return f"Mesh2D(dp={self.dp_size}, pp={self.pp_size}, rank={self.rank}, dp_idx={self.dp_index}, pp_idx={self.pp_index})"
+
+
+def choose_mesh(world: int, pp_size: int, dp_size: int = 0):
+    """Default hybrid layout: pp fixed (reference: 2), dp = world // pp
+    (3x2 on the reference's 6 GPUs, 4x2 on one 8xMI355X node)."""
+    if dp_size and dp_size * pp_size == world:
+        return dp_size, pp_size
+    if world % pp_size:
+        raise ValueError(f"world size {world} is not divisible by pp_size {pp_size}")
+    return world // pp_size, pp_size
+
+
+# --------------------------------------------------------------------------------------
+# collective wrappers
+# --------------------------------------------------------------------------------------
+def _log(op: str, t: torch.Tensor, group) -> None:
+    if _CHECKER is not None:
+        _CHECKER.record(op, t, group)
+
+
+def _is_gloo(group) -> bool:
+    return backend_of(group) == "gloo"
+
+
+def all_reduce(t: torch.Tensor, op: str = "sum", group=None, async_op: bool = False):
+    """In-place all-reduce; ``op`` in {sum, avg, max}.  AVG is native on RCCL, emulated on gloo."""
+    if get_world_size(group) == 1 and not is_dist():
+        return None
+    _log("all_reduce", t, group)
+    if op == "avg":
+        if _is_gloo(group):
+            w = dist.all_reduce(t, dist.ReduceOp.SUM, group=group, async_op=False)
+            t.div_(get_world_size(group))
+            return None
+        return dist.all_reduce(t, dist.ReduceOp.AVG, group=group, async_op=async_op)
+    red = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op]
+    return dist.all_reduce(t, red, group=group, async_op=async_op)
+
+
+def broadcast(t: torch.Tensor, src: int, group=None, async_op: bool = False):
+    """``src`` is a *global* rank (like torch)."""
+    if not is_dist():
+        return None
+    _log("broadcast", t, group)
+    return dist.broadcast(t, src=src, group=group, async_op=async_op)
+
+
+def all_gather_flat(t: torch.Tensor, group=None) -> torch.Tensor:
+    """Concatenate equally-shaped tensors of every rank along dim 0 (one flat collective,
+    replaces the list-form ``all_gather`` of ddp.py:196-197,249-253)."""
+    w = get_world_size(group)
+    if w == 1:
+        return t
+    t = t.contiguous()
+    _log("all_gather", t, group)
+    out = torch.empty((w * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return out
+
+
+def all_gather_into(out: torch.Tensor, shard: torch.Tensor, group=None, async_op: bool = False):
+    """``out`` (W*n) <- concat of every rank's ``shard`` (n).  In-place form allowed
+    (``shard`` a view of ``out`` at this rank's offset), as RCCL defines it."""
+    _log("all_gather", shard, group)
+    if _is_gloo(group):
+        # gloo: out-of-place only
+        tmp = shard.clone()
+        w = dist.all_gather_into_tensor(out, tmp, group=group, async_op=False)
+        return None
+    return dist.all_gather_into_tensor(out, shard, group=group, async_op=async_op)
+
+
+def reduce_scatter_into(shard: torch.Tensor, full: torch.Tensor, op: str = "sum", group=None,
+                        async_op: bool = False):
+    """``shard`` (n) <- this rank's slice of the reduction of every rank's ``full`` (W*n).
+    In-place form allowed (``shard`` a view of ``full``).  gloo has no reduce-scatter:
+    emulate with all-reduce + slice (test transport only)."""
+    _log("reduce_scatter", full, group)
+    w = get_world_size(group)
+    if _is_gloo(group):
+        dist.all_reduce(full, dist.ReduceOp.SUM, group=group)
+        r = get_rank(group)
+        n = shard.numel()
+        if shard.data_ptr() != full[r * n:(r + 1) * n].data_ptr():
+            shard.copy_(full[r * n:(r + 1) * n])
+        if op == "avg":
+            shard.div_(w)
+        return None
+    red = dist.ReduceOp.AVG if op == "avg" else dist.ReduceOp.SUM
+    return dist.reduce_scatter_tensor(shard, full, op=red, group=group, async_op=async_op)
+
+
+def barrier(group=None) -> None:
+    if is_dist():
+        if backend_of(group) == "nccl":
+            dist.barrier(group=group, device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier(group=group)
+
+
+def broadcast_flag(flag: bool, src: int, device, group=None) -> bool:
+    """Scalar bool broadcast (reference: save_model flag, ddp.py:223, pp.py:243, ddp_n_pp.py:275)."""
+    if not is_dist():
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    broadcast(t, src=src, group=group)
+    return bool(t.item())
+
+
+# --------------------------------------------------------------------------------------
+# collective-order checker
+# --------------------------------------------------------------------------------------
+class CollectiveChecker:
+    """Records the sequence of collectives issued by this rank; ``verify`` all-gathers a
+    digest over a group and raises if any member issued a different sequence - the failure
+    mode that otherwise shows up as a hang inside RCCL."""
+
+    def __init__(self) -> None:
+        self.log: List[str] = []
+
+    def record(self, op: str, t: torch.Tensor, group) -> None:
+        gid = "world" if group is None else f"g{get_world_size(group)}"
+        self.log.append(f"{op}:{t.numel()}:{t.dtype}:{gid}")
+
+    def digest(self) -> int:
+        h = hashlib.sha1("|".join(self.log).encode()).digest()
+        return int.from_bytes(h[:7], "little")
+
+    def verify(self, device="cpu", group=None, reset: bool = True) -> None:
+        global _CHECKER
+        saved, _CHECKER = _CHECKER, None          # do not record the checker's own traffic
+        try:
+            mine = torch.tensor([self.digest(), len(self.log)], dtype=torch.int64, device=device)
+            everyone = all_gather_flat(mine.reshape(1, 2), group)
+        finally:
+            _CHECKER = saved
+        if not bool((everyone == everyone[0]).all()):
+            raise RuntimeError(
+                f"collective sequence mismatch across ranks: {everyone.tolist()} (rank {get_rank()} "
+                f"issued {len(self.log)} ops, last: {self.log[-3:]})")
+        if reset:
+            self.log.clear()
+
+
+def enable_checker() -> CollectiveChecker:
+    global _CHECKER
+    _CHECKER = CollectiveChecker()
+    return _CHECKER
+
+
+def disable_checker() -> None:
+    global _CHECKER
+    _CHECKER = None

@@ -1,0 +1,288 @@
+"""Datasets, samplers and loaders.
+
+Reference behaviour (single.py:38-65, duplicated in all four trainers): a CSV of
+``(id, diagnosis)`` rows, ``root/{id}.png`` decoded to uint8 CHW and divided by
+255 on the CPU inside the DataLoader worker; the fp32 batch (9 MB at B=15) is
+then copied host->device synchronously from pageable memory (ddp.py:181-182).
+
+MI355X-first changes:
+  * batches travel as **uint8** (4x fewer PCIe bytes) from pinned memory and are
+    normalised (``/255``) and re-laid-out NCHW->NHWC by one HIP kernel on the GPU
+    (``ddl.ops.normalize_input``); ``Normalize`` is still provided for the CPU path.
+  * ``SyntheticAptos`` stands in for the (unshipped) APTOS-2019 images: same
+    shape/dtype/label range, deterministic per index, class-dependent so that a
+    model can actually learn it in smoke tests.
+  * ``DeviceSyntheticLoader`` generates batches directly in HBM for benchmarks so
+    that the measured number is the training step, not the host input pipeline
+    (the reference is input-bound: SURVEY 6.2).
+  * samplers are explicit: ``ShardedSampler`` (DDP / hybrid: per-dp-rank shard,
+    epoch-seeded shuffle, drop_last) and the same class with ``num_replicas=1``
+    and a fixed seed for pipeline stages, which makes the "every stage iterates
+    the same permutation" contract of pp.py:363-371 explicit instead of relying
+    on torch.Generator's default seed.
+"""
+from __future__ import annotations
+
+import csv
+import math
+import os
+from pathlib import Path
+from typing import Iterator, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset, Sampler
+
+
+class Normalize:
+    """uint8 -> float32 in [0,1] (reference: single.py:38-42; no mean/std, no augmentation)."""
+
+    def __call__(self, img: torch.Tensor) -> torch.Tensor:
+        return (img / 255.0).float()
+
+
+def read_png(path) -> torch.Tensor:
+    """Decode a PNG to a uint8 CHW tensor (torchvision.io.read_image is not installed)."""
+    from PIL import Image
+
+    with Image.open(path) as im:
+        arr = np.asarray(im.convert("RGB"), dtype=np.uint8)
+    return torch.from_numpy(arr.copy()).permute(2, 0, 1).contiguous()
+
+
+def write_png(path, chw_uint8: torch.Tensor) -> None:
+    from PIL import Image
+
+    Image.fromarray(chw_uint8.permute(1, 2, 0).contiguous().numpy(), mode="RGB").save(path)
+
+
+class AptosDataset(Dataset):
+    """CSV-indexed PNG folder (reference: single.py:45-65)."""
+
+    def __init__(self, csv_file, root_dir, filename_col: str, label_col: str, transform=None) -> None:
+        self.root_dir = Path(root_dir)
+        self.transform = transform
+        with open(csv_file, newline="") as f:
+            rows = list(csv.DictReader(f))
+        self.names: List[str] = [r[filename_col] for r in rows]
+        self.labels: List[int] = [int(r[label_col]) for r in rows]
+
+    def __len__(self) -> int:
+        return len(self.names)
+
+    def __getitem__(self, idx: int) -> Tuple[torch.Tensor, int]:
+        img = read_png(self.root_dir / f"{self.names[idx]}.png")
+        if self.transform is not None:
+            img = self.transform(img)
+        return img, self.labels[idx]
+
+
+class SyntheticAptos(Dataset):
+    """Deterministic stand-in for APTOS-2019: uint8 [3,S,S] images, labels in [0, C).
+
+    Each class has a fixed low-frequency template; a sample is template + noise,
+    so the task is learnable (train accuracy rises within an epoch) but not trivial.
+    """
+
+    def __init__(self, n: int, image_size: int = 224, num_classes: int = 5, seed: int = 0,
+                 transform=None, noise: float = 48.0) -> None:
+        self.n = n
+        self.size = image_size
+        self.num_classes = num_classes
+        self.seed = seed
+        self.transform = transform
+        self.noise = noise
+        g = torch.Generator().manual_seed(seed * 7919 + 13)
+        coarse = torch.rand(num_classes, 3, 7, 7, generator=g)
+        self.templates = torch.nn.functional.interpolate(
+            coarse, size=(image_size, image_size), mode="bilinear", align_corners=False) * 255.0
+        self.labels = torch.randint(0, num_classes, (n,), generator=g).tolist()
+
+    def __len__(self) -> int:
+        return self.n
+
+    def __getitem__(self, idx: int) -> Tuple[torch.Tensor, int]:
+        label = self.labels[idx]
+        g = torch.Generator().manual_seed(self.seed * 1000003 + idx)
+        img = self.templates[label] + self.noise * torch.randn(3, self.size, self.size, generator=g)
+        img = img.clamp_(0, 255).to(torch.uint8)
+        if self.transform is not None:
+            img = self.transform(img)
+        return img, label
+
+
+class ShardedSampler(Sampler[int]):
+    """Epoch-seeded shuffle, sharded over ``num_replicas`` (drop_last), explicit seed.
+
+    Same contract as DistributedSampler(shuffle=True, drop_last=True) used by the
+    reference (ddp.py:343,353): every replica sees ``len(dataset) // num_replicas``
+    samples, disjoint across replicas, reshuffled by ``set_epoch``.
+    """
+
+    def __init__(self, n: int, num_replicas: int = 1, rank: int = 0, shuffle: bool = True,
+                 seed: int = 0, drop_last: bool = True) -> None:
+        if not 0 <= rank < num_replicas:
+            raise ValueError(f"rank {rank} out of range for {num_replicas} replicas")
+        self.n, self.num_replicas, self.rank = n, num_replicas, rank
+        self.shuffle, self.seed, self.drop_last = shuffle, seed, drop_last
+        self.epoch = 0
+        if drop_last:
+            self.num_samples = n // num_replicas
+        else:
+            self.num_samples = math.ceil(n / num_replicas)
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = epoch
+
+    def __len__(self) -> int:
+        return self.num_samples
+
+    def __iter__(self) -> Iterator[int]:
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            order = torch.randperm(self.n, generator=g).tolist()
+        else:
+            order = list(range(self.n))
+        total = self.num_samples * self.num_replicas
+        if len(order) < total:      # pad (drop_last=False)
+            order += order[: total - len(order)]
+        order = order[:total]
+        return iter(order[self.rank: total: self.num_replicas])
+
+
+def _collate_uint8(batch):
+    xs = torch.stack([b[0] for b in batch])
+    ys = torch.tensor([int(b[1]) for b in batch], dtype=torch.int64)
+    return xs, ys
+
+
+class HostLoader:
+    """DataLoader wrapper: known length/batch size up front (no ``next(iter())`` probe per
+    epoch as in ddp.py:177), pinned uint8 batches, ``set_epoch`` passthrough."""
+
+    def __init__(self, dataset: Dataset, batch_size: int, sampler: ShardedSampler,
+                 num_workers: int = 2, drop_last: bool = True, pin_memory: bool = False) -> None:
+        self.dataset, self.batch_size, self.sampler = dataset, batch_size, sampler
+        self.drop_last = drop_last
+        self.loader = DataLoader(dataset, batch_size=batch_size, sampler=sampler,
+                                 num_workers=num_workers, drop_last=drop_last,
+                                 collate_fn=_collate_uint8, pin_memory=pin_memory,
+                                 persistent_workers=num_workers > 0)
+
+    def set_epoch(self, epoch: int) -> None:
+        self.sampler.set_epoch(epoch)
+
+    def __len__(self) -> int:
+        return len(self.loader)
+
+    def __iter__(self):
+        return iter(self.loader)
+
+    def batch_sizes(self) -> List[int]:
+        """Batch size of every step of an epoch - lets pipeline stages that load no data
+        still know the shapes they will receive."""
+        n = len(self.sampler)
+        full, rem = divmod(n, self.batch_size)
+        sizes = [self.batch_size] * full
+        if rem and not self.drop_last:
+            sizes.append(rem)
+        return sizes
+
+
+class DeviceSyntheticLoader:
+    """Synthetic uint8 batches generated directly on the device (benchmark input)."""
+
+    def __init__(self, steps: int, batch_size: int, device, image_size: int = 224,
+                 num_classes: int = 5, seed: int = 0, pool: int = 4) -> None:
+        self.steps, self.batch_size, self.device = steps, batch_size, torch.device(device)
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        self.pool = []
+        for _ in range(pool):
+            x = torch.randint(0, 256, (batch_size, 3, image_size, image_size), dtype=torch.uint8, generator=g)
+            y = torch.randint(0, num_classes, (batch_size,), dtype=torch.int64, generator=g)
+            self.pool.append((x.to(self.device), y.to(self.device)))
+
+    def set_epoch(self, epoch: int) -> None:
+        pass
+
+    def __len__(self) -> int:
+        return self.steps
+
+    def __iter__(self):
+        for i in range(self.steps):
+            yield self.pool[i % len(self.pool)]
+
+    def batch_sizes(self) -> List[int]:
+        return [self.batch_size] * self.steps
+
+
+def use_synthetic(cfg) -> bool:
+    if cfg.synthetic == "on":
+        return True
+    if cfg.synthetic == "off":
+        return False
+    return not (Path(cfg.data_dir) / "train.csv").exists()
+
+
+def build_datasets(cfg, transform=None):
+    """(train, eval) datasets: APTOS from ``cfg.data_dir`` or the synthetic stand-in."""
+    if use_synthetic(cfg):
+        seed = 0 if cfg.seed is None else cfg.seed
+        train = SyntheticAptos(cfg.train_samples, cfg.image_size, cfg.num_classes, seed=seed, transform=transform)
+        test = SyntheticAptos(cfg.eval_samples, cfg.image_size, cfg.num_classes, seed=seed, transform=transform)
+        # same templates, disjoint noise / labels
+        test.seed = seed + 1
+        g = torch.Generator().manual_seed(seed * 31 + 5)
+        test.labels = torch.randint(0, cfg.num_classes, (cfg.eval_samples,), generator=g).tolist()
+        return train, test
+    d = Path(cfg.data_dir)
+    train = AptosDataset(d / "train.csv", d / "train_images", "new_id_code", "diagnosis", transform)
+    test = AptosDataset(d / "test.csv", d / "test_images", "id_code", "diagnosis", transform)
+    return train, test
+
+
+def build_loaders(cfg, dp_rank: int = 0, dp_size: int = 1, device=None, shared_order: bool = False):
+    """Train/eval loaders for one process.
+
+    ``shared_order`` (pipeline stages): every rank iterates the *same* permutation
+    (fixed seed), the explicit form of the reference's pp.py generator contract.
+    """
+    seed = 0 if cfg.seed is None else cfg.seed
+    pin = device is not None and torch.device(device).type == "cuda"
+    if cfg.device_data and pin:
+        steps = (cfg.train_samples // dp_size) // cfg.batch_size
+        esteps = (cfg.eval_samples // dp_size) // cfg.batch_size
+        if cfg.max_steps:
+            steps = min(steps, cfg.max_steps)
+        return (DeviceSyntheticLoader(steps, cfg.batch_size, device, cfg.image_size, cfg.num_classes, seed + dp_rank),
+                DeviceSyntheticLoader(max(esteps, 1), cfg.batch_size, device, cfg.image_size, cfg.num_classes,
+                                      seed + 1000 + dp_rank))
+    train_ds, test_ds = build_datasets(cfg)
+    tr_s = ShardedSampler(len(train_ds), dp_size, dp_rank, shuffle=True, seed=seed, drop_last=True)
+    # reference eval sampler: shuffle=True, drop_last=True (ddp.py:353); --eval-all keeps the tail
+    te_s = ShardedSampler(len(test_ds), dp_size, dp_rank, shuffle=True, seed=seed + 1,
+                          drop_last=not cfg.eval_all)
+    # reference: train DataLoader drop_last only in pp/hybrid (pp.py:366-372); single/ddp keep the tail
+    drop_train = cfg.strategy in ("pp", "ddpnpp")
+    train = HostLoader(train_ds, cfg.batch_size, tr_s, cfg.num_workers, drop_last=drop_train, pin_memory=pin)
+    test = HostLoader(test_ds, cfg.batch_size, te_s, cfg.num_workers,
+                      drop_last=(cfg.strategy in ("pp", "ddpnpp")) and not cfg.eval_all, pin_memory=pin)
+    return train, test
+
+
+def make_png_dataset(root, n_train: int, n_test: int, image_size: int = 32, num_classes: int = 5, seed: int = 0):
+    """Write a tiny APTOS-layout dataset (CSV + PNG folders) - used by tests to exercise
+    the real ``AptosDataset`` path without the private data."""
+    root = Path(root)
+    for split, n, col in (("train", n_train, "new_id_code"), ("test", n_test, "id_code")):
+        ds = SyntheticAptos(n, image_size, num_classes, seed=seed + (split == "test"))
+        os.makedirs(root / f"{split}_images", exist_ok=True)
+        with open(root / f"{split}.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow([col, "diagnosis"])
+            for i in range(n):
+                img, label = ds[i]
+                name = f"{split}_{i:05d}"
+                write_png(root / f"{split}_images" / f"{name}.png", img)
+                w.writerow([name, label])
+    return root
