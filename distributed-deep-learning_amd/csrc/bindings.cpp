@@ -1,0 +1,79 @@
+// pybind11 / ATen face of the gfx950 kernels: shape checks on the host (a faulting kernel can
+// reset the whole node), then a launch on PyTorch's current HIP stream.  No allocation happens
+// inside the launchers themselves; outputs are allocated here through the caching allocator,
+// which is graph-capture safe.
+#include <torch/extension.h>
+#include <c10/hip/HIPStream.h>
+#include <c10/hip/HIPGuard.h>
+
+#include "ddl_kernels.h"
+
+namespace {
+
+inline hipStream_t cur_stream() { return c10::hip::getCurrentHIPStream().stream(); }
+
+#define CHECK_DEV(x) TORCH_CHECK((x).is_cuda(), #x " must be a GPU tensor")
+#define CHECK_CONTIG(x) TORCH_CHECK((x).is_contiguous(), #x " must be contiguous")
+#define CHECK_F32(x) TORCH_CHECK((x).scalar_type() == at::kFloat, #x " must be float32")
+
+at::Tensor normalize_u8(const at::Tensor& x, bool nhwc) {
+  CHECK_DEV(x); CHECK_CONTIG(x);
+  TORCH_CHECK(x.scalar_type() == at::kByte && x.dim() == 4, "normalize_u8: uint8 [B,C,H,W] expected");
+  c10::hip::HIPGuard guard(x.device());
+  const int B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+  auto out = nhwc ? at::empty({B, H, W, C}, x.options().dtype(at::kFloat))
+                  : at::empty({B, C, H, W}, x.options().dtype(at::kFloat));
+  ddl::launch_normalize_u8(x.data_ptr<uint8_t>(), out.data_ptr<float>(), B, C, H, W, nhwc, cur_stream());
+  return out;
+}
+
+std::vector<at::Tensor> ce_fwd_bwd(const at::Tensor& logits, const at::Tensor& targets) {
+  CHECK_DEV(logits); CHECK_CONTIG(logits); CHECK_F32(logits);
+  CHECK_DEV(targets); CHECK_CONTIG(targets);
+  TORCH_CHECK(logits.dim() == 2 && targets.dim() == 1 && targets.size(0) == logits.size(0),
+              "ce_fwd_bwd: logits [B,C], targets [B]");
+  TORCH_CHECK(targets.scalar_type() == at::kLong, "targets must be int64");
+  c10::hip::HIPGuard guard(logits.device());
+  const int B = logits.size(0), C = logits.size(1);
+  auto loss = at::empty({}, logits.options());
+  auto dlogits = at::empty_like(logits);
+  auto preds = at::empty({B}, targets.options());
+  ddl::launch_ce_fwd_bwd(logits.data_ptr<float>(), targets.data_ptr<int64_t>(), loss.data_ptr<float>(),
+                         dlogits.data_ptr<float>(), preds.data_ptr<int64_t>(), B, C, cur_stream());
+  return {loss, dlogits, preds};
+}
+
+void adam_step(at::Tensor p, at::Tensor g, at::Tensor m, at::Tensor v, at::Tensor step_t, at::Tensor aux,
+               double lr, double b1, double b2, double eps, double wd, bool zero_grad,
+               std::vector<int64_t> starts, std::vector<int64_t> ends) {
+  for (const at::Tensor* t : {&p, &g, &m, &v, &step_t, &aux}) {
+    CHECK_DEV(*t); CHECK_CONTIG(*t); CHECK_F32(*t);
+  }
+  const int64_t n = p.numel();
+  TORCH_CHECK(g.numel() == n && m.numel() == n && v.numel() == n, "adam_step: arena size mismatch");
+  TORCH_CHECK(step_t.numel() >= 1 && aux.numel() >= 2, "adam_step: step_t[1], aux[2] expected");
+  TORCH_CHECK(starts.size() == ends.size(), "adam_step: ranges");
+  TORCH_CHECK((reinterpret_cast<uintptr_t>(p.data_ptr()) % 16) == 0, "arena must be 16-byte aligned");
+  c10::hip::HIPGuard guard(p.device());
+  hipStream_t s = cur_stream();
+  ddl::launch_adam_inc_step(step_t.data_ptr<float>(), aux.data_ptr<float>(), b1, b2, s);
+  for (size_t i = 0; i < starts.size(); ++i) {
+    TORCH_CHECK(0 <= starts[i] && starts[i] <= ends[i] && ends[i] <= n, "adam_step: range out of bounds");
+    TORCH_CHECK(starts[i] % 4 == 0 && (ends[i] - starts[i]) % 4 == 0, "adam_step: ranges must be float4 aligned");
+    ddl::launch_adam_flat(p.data_ptr<float>(), g.data_ptr<float>(), m.data_ptr<float>(), v.data_ptr<float>(),
+                          aux.data_ptr<float>(), starts[i], ends[i], (float)lr, (float)b1, (float)b2,
+                          (float)eps, (float)wd, zero_grad, s);
+  }
+}
+
+}  // namespace
+
+void register_conv_ops(pybind11::module_& m);   // conv_bindings.cpp
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.doc() = "hand-written gfx950 (MI355X) kernels of the ddl framework";
+  m.def("normalize_u8", &normalize_u8, "uint8 NCHW -> fp32/255 (NHWC or NCHW)");
+  m.def("ce_fwd_bwd", &ce_fwd_bwd, "fused softmax+CE loss, dlogits, argmax");
+  m.def("adam_step", &adam_step, "flat fused Adam (+zero_grad)");
+  register_conv_ops(m);
+}

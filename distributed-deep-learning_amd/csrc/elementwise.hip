@@ -1,0 +1,159 @@
+// Bandwidth-bound helper kernels for gfx950 (wave64): input normalisation (K14), fused
+// softmax+cross-entropy(+argmax) forward/backward (K10/K11), flat fused Adam (+zero_grad) (K12/K13).
+// Reference ops: Normalize (single.py:38-42), F.cross_entropy + torch.argmax (single.py:139-141),
+// optim.Adam defaults (single.py:108,305).
+#include "ddl_kernels.h"
+
+namespace ddl {
+
+// ---------------------------------------------------------------------------------------
+// K14: uint8 NCHW -> fp32/255 NHWC|NCHW.  One thread per pixel: per-plane byte reads are
+// coalesced across the wave, the NHWC write is 12 contiguous bytes per lane.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) normalize_u8_kernel(const uint8_t* __restrict__ in,
+                                                           float* __restrict__ out, int C, int HW,
+                                                           long total_px, bool nhwc) {
+  const float k = 1.0f / 255.0f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total_px; i += (long)gridDim.x * 256L) {
+    long b = i / HW;
+    long px = i - b * HW;
+    const uint8_t* src = in + b * C * HW + px;
+    if (nhwc) {
+      float* dst = out + i * C;
+      for (int c = 0; c < C; ++c) dst[c] = (float)src[(long)c * HW] * k;
+    } else {
+      float* dst = out + b * C * HW + px;
+      for (int c = 0; c < C; ++c) dst[(long)c * HW] = (float)src[(long)c * HW] * k;
+    }
+  }
+}
+
+void launch_normalize_u8(const uint8_t* in, float* out, int B, int C, int H, int W, bool nhwc,
+                         hipStream_t s) {
+  long total = (long)B * H * W;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 256 * 8) grid = 256 * 8;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(normalize_u8_kernel, dim3(grid), dim3(256), 0, s, in, out, C, H * W, total, nhwc);
+}
+
+// ---------------------------------------------------------------------------------------
+// K10/K11: one thread per row (C is tiny: 5 classes).  loss = mean_i (lse_i - z_i[t_i]);
+// dlogits = (softmax - onehot) / B; preds = argmax (first max, like torch.argmax).
+// Block partial sums go through a wave shuffle + LDS reduction, one atomic per block.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ce_fwd_bwd_kernel(const float* __restrict__ logits,
+                                                         const int64_t* __restrict__ targets,
+                                                         float* __restrict__ loss,
+                                                         float* __restrict__ dlogits,
+                                                         int64_t* __restrict__ preds, int B, int C) {
+  __shared__ float wave_sums[4];
+  float local = 0.f;
+  const float invB = 1.0f / (float)B;
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < B; r += gridDim.x * 256) {
+    const float* z = logits + (long)r * C;
+    float mx = z[0];
+    int arg = 0;
+    for (int c = 1; c < C; ++c) {
+      float v = z[c];
+      if (v > mx) { mx = v; arg = c; }
+    }
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) sum += __expf(z[c] - mx);
+    float lse = mx + __logf(sum);
+    int t = (int)targets[r];
+    local += lse - z[t];
+    float inv = 1.0f / sum;
+    float* dz = dlogits + (long)r * C;
+    for (int c = 0; c < C; ++c) {
+      float p = __expf(z[c] - mx) * inv;
+      dz[c] = (p - (c == t ? 1.f : 0.f)) * invB;
+    }
+    preds[r] = arg;
+  }
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) wave_sums[wid] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+    atomicAdd(loss, tot * invB);
+  }
+}
+
+void launch_ce_fwd_bwd(const float* logits, const int64_t* targets, float* loss, float* dlogits,
+                       int64_t* preds, int B, int C, hipStream_t s) {
+  hipMemsetAsync(loss, 0, sizeof(float), s);
+  int grid = (B + 255) / 256;
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(grid), dim3(256), 0, s, logits, targets, loss, dlogits,
+                     preds, B, C);
+}
+
+// ---------------------------------------------------------------------------------------
+// K12/K13: Adam over a flat arena.  16 B per lane per array (float4), 4 reads + 3 writes per
+// element (+1 write when zeroing grads) - pure HBM streaming.  The step counter is a device
+// float so that the launch sequence is identical every step (hipGraph replay).
+// ---------------------------------------------------------------------------------------
+// Single-thread prologue: step += 1 and the bias corrections in double precision
+// (aux[0] = 1 - b1^t, aux[1] = 1/sqrt(1 - b2^t)), so the streaming kernel does no pow().
+__global__ void adam_inc_step_kernel(float* step_t, float* aux, double b1, double b2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float t = step_t[0] + 1.0f;
+    step_t[0] = t;
+    aux[0] = (float)(1.0 - pow(b1, (double)t));
+    aux[1] = (float)(1.0 / sqrt(1.0 - pow(b2, (double)t)));
+  }
+}
+
+void launch_adam_inc_step(float* step_t, float* aux, double b1, double b2, hipStream_t s) {
+  hipLaunchKernelGGL(adam_inc_step_kernel, dim3(1), dim3(64), 0, s, step_t, aux, b1, b2);
+}
+
+__device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v, float lr_c, float b1,
+                                         float b2, float eps, float wd, float inv_sqrt_bc2) {
+  float gg = g;
+  if (wd != 0.f) gg += wd * p;
+  m = b1 * m + (1.f - b1) * gg;
+  v = b2 * v + (1.f - b2) * gg * gg;
+  float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+  p -= lr_c * (m / denom);
+}
+
+__global__ void __launch_bounds__(256) adam_flat_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        const float* __restrict__ aux, long n4,
+                                                        float lr, float b1, float b2, float eps,
+                                                        float wd, bool zero_grad) {
+  const float lr_c = lr / aux[0];
+  const float inv_sqrt_bc2 = aux[1];
+  float4* p4 = reinterpret_cast<float4*>(p);
+  float4* g4 = reinterpret_cast<float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
+    float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+    adam_one(pp.x, gg.x, mm.x, vv.x, lr_c, b1, b2, eps, wd, inv_sqrt_bc2);
+    adam_one(pp.y, gg.y, mm.y, vv.y, lr_c, b1, b2, eps, wd, inv_sqrt_bc2);
+    adam_one(pp.z, gg.z, mm.z, vv.z, lr_c, b1, b2, eps, wd, inv_sqrt_bc2);
+    adam_one(pp.w, gg.w, mm.w, vv.w, lr_c, b1, b2, eps, wd, inv_sqrt_bc2);
+    p4[i] = pp;
+    m4[i] = mm;
+    v4[i] = vv;
+    if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+void launch_adam_flat(float* p, float* g, float* m, float* v, const float* aux, int64_t start,
+                      int64_t end, float lr, float b1, float b2, float eps, float wd, bool zero_grad,
+                      hipStream_t s) {
+  // arena ranges are multiples of 64 elements (FlatArena alignment) -> float4-safe
+  long n4 = (long)(end - start) / 4;
+  if (n4 <= 0) return;
+  long grid = (n4 + 255) / 256;
+  if (grid > 256 * 8) grid = 256 * 8;
+  hipLaunchKernelGGL(adam_flat_kernel, dim3((int)grid), dim3(256), 0, s, p + start, g + start, m + start,
+                     v + start, aux, n4, lr, b1, b2, eps, wd, zero_grad);
+}
+
+}  // namespace ddl

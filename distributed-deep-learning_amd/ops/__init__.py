@@ -99,8 +99,8 @@ def cross_entropy(logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------
 # K12/K13: flat fused Adam (+ zero_grad)
 # --------------------------------------------------------------------------------------
-def adam_step_flat(p, g, m, v, step_t, lr, b1, b2, eps, wd, zero_grad: bool,
+def adam_step_flat(p, g, m, v, step_t, aux_t, lr, b1, b2, eps, wd, zero_grad: bool,
                    ranges: Sequence[Tuple[int, int]]) -> None:
     ext = require_ext()
-    ext.adam_step(p, g, m, v, step_t, float(lr), float(b1), float(b2), float(eps), float(wd),
+    ext.adam_step(p, g, m, v, step_t, aux_t, float(lr), float(b1), float(b2), float(eps), float(wd),
                   bool(zero_grad), [int(s) for s, _ in ranges], [int(e) for _, e in ranges])

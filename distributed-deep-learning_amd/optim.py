@@ -66,6 +66,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg_sq = arena.like(0.0)
         # device-resident step counter (float32 like torch's per-param ``step`` tensors)
         self.step_t = torch.zeros(1, dtype=torch.float32, device=arena.device)
+        self.aux_t = torch.ones(2, dtype=torch.float32, device=arena.device)   # bias corrections (device)
         self._host_step = 0
         self.shard = shard
         for i, p in enumerate(arena.params):
@@ -96,7 +97,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._host_step += 1
         if a.device.type == "cuda":
             from . import ops
-            ops.adam_step_flat(a.flat_param, a.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_t,
+            ops.adam_step_flat(a.flat_param, a.flat_grad, self.exp_avg, self.exp_avg_sq, self.step_t, self.aux_t,
                                lr, b1, b2, eps, wd, zero_grad, self._ranges())
         else:
             self.step_t += 1
@@ -115,10 +116,9 @@ class FusedAdam(torch.optim.Optimizer):
     def state_dict(self) -> Dict[str, Any]:
         sd = super().state_dict()
         # per-parameter ``step`` must be independent tensors in the serialised form
-        for st in sd["state"].values():
-            st["step"] = st["step"].detach().clone()
-            st["exp_avg"] = st["exp_avg"].detach().clone()
-            st["exp_avg_sq"] = st["exp_avg_sq"].detach().clone()
+        # (the base class hands out the live per-param dicts: build new ones, never edit those)
+        sd["state"] = {k: {n: (t.detach().clone() if isinstance(t, torch.Tensor) else t)
+                           for n, t in st.items()} for k, st in sd["state"].items()}
         return sd
 
     @torch.no_grad()

@@ -1,0 +1,105 @@
+"""Each of the reference's entry scripts runs one short epoch on synthetic data on CPU
+(BASELINE.json configs 1-2)."""
+import csv
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from dist_utils import ROOT, free_port
+
+SMALL = ["--epochs", "1", "--max-steps", "2", "--train-samples", "64", "--eval-samples", "32",
+         "--image-size", "64", "--num-workers", "0", "--device", "cpu"]
+
+
+def _env(tmp_path):
+    env = dict(os.environ, DDL_LOG_DIR=str(tmp_path / "logs"), DDL_CKPT_DIR=str(tmp_path / "ckpt"),
+               DDL_DATA_DIR=str(tmp_path / "nodata"), OMP_NUM_THREADS="1", TORCHX_JOB_ID="k8s://ns/job-123")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    return env
+
+
+def _run(cmd, env, timeout=420):
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-4000:]
+    return r.stdout
+
+
+def _torchrun(n, script, args, env):
+    return _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+                 "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script, *args], env)
+
+
+def _metric_files(tmp_path):
+    d = tmp_path / "logs" / "by_job_id" / "job-123"
+    return {p.stem: list(csv.reader(open(p))) for p in d.glob("*.csv")}
+
+
+ALL_METRICS = {"epoch_time", "loss", "train_accuracy", "val_loss", "val_accuracy", "macro_f1", "weighted_f1",
+               "macro_precision", "weighted_precision", "macro_recall", "weighted_recall", "qwk"}
+
+
+def test_single_epoch_and_resume(tmp_path):
+    env = _env(tmp_path)
+    out = _run([sys.executable, "single.py", *SMALL, "--batch-size", "8", "--save-every", "1"], env)
+    assert "Epoch 0 | Training Accuracy" in out and "Saved snapshot" in out
+    files = _metric_files(tmp_path)
+    assert set(files) == ALL_METRICS                               # the reference's 12 per-epoch metrics
+    assert files["loss"][0][1:6] == ["job-123", "0", "0", "job-123", "0"]
+    assert (tmp_path / "ckpt" / "single" / "job-123" / "epoch_0" / ".metadata").exists()
+    out = _run([sys.executable, "single.py", *SMALL[2:], "--epochs", "2", "--batch-size", "8",
+                "--snapshot-job-id", "job-123", "--snapshot-epoch", "0"], env)
+    assert "Resuming training from snapshot at Epoch 1" in out and "Starting Epoch 1" in out
+    assert "Starting Epoch 0" not in out
+
+
+def test_ddp_world2(tmp_path):
+    out = _torchrun(2, "ddp.py", [*SMALL, "--batch-size", "8", "--profile", "--check-collectives"], _env(tmp_path))
+    assert "[GPU0] Epoch 0 | Validation QWK" in out
+    files = _metric_files(tmp_path)
+    assert set(files) == ALL_METRICS and all(r[2] == "0" for r in files["qwk"])   # rank 0 logs
+
+
+@pytest.mark.parametrize("schedule", ["1f1b", "gpipe"])
+def test_pp_two_stage(tmp_path, schedule):
+    out = _torchrun(2, "pp.py", [*SMALL, "--batch-size", "10", "--schedule", schedule], _env(tmp_path))
+    assert "[GPU1] Epoch 0 | Validation QWK" in out                # last stage logs (pp.py:222-238)
+    assert all(r[2] == "1" for r in _metric_files(tmp_path)["loss"])
+
+
+def test_pp_four_stage(tmp_path):
+    from ddl.models.densenet import default_split_points
+    out = _torchrun(4, "pp.py", [*SMALL, "--batch-size", "10", "--split-points", *default_split_points(4)],
+                    _env(tmp_path))
+    assert "[GPU3] Epoch 0 | Validation QWK" in out
+
+
+def test_hybrid_2x2_with_snapshot(tmp_path):
+    out = _torchrun(4, "ddp_n_pp.py", [*SMALL, "--batch-size", "10", "--save-every", "1"], _env(tmp_path))
+    assert "[GPU1] Epoch 0 | Validation QWK" in out                # last stage of dp-rank 0 (mesh[0][-1])
+    from ddl import checkpoint as ck
+    keys = ck.read_keys(str(tmp_path / "ckpt" / "ddpnpp" / "job-123" / "epoch_0"))
+    assert "app.model0.features.conv0.weight" in keys              # stage-suffixed keys (ddp_n_pp.py:94-95)
+    assert "app.model1.classifier.weight" in keys and "app.optim1.state.classifier.bias.exp_avg" in keys
+
+
+def test_communication_time_ping_and_sweep(tmp_path):
+    env = _env(tmp_path)
+    out = _torchrun(2, "communication_time.py",
+                    ["--iters", "5", "--numel", "4096", "--sweep", "--max-bytes", "16384", "--device", "cpu",
+                     "--log-dir", str(tmp_path / "logs"), "--json", str(tmp_path / "sweep.json")], env)
+    rows = list(csv.reader(open(tmp_path / "logs" / "communication_time.csv")))
+    assert len(rows) == 5 and rows[0][0] == "job-123" and rows[4][1] == "4"        # job_id,i,ms
+    res = json.load(open(tmp_path / "sweep.json"))
+    assert {r["op"] for r in res["sweep"]} == {"send_recv", "all_reduce", "rs_ag"}
+
+
+def test_mesh_smoke_and_split_explorer(tmp_path):
+    out = _torchrun(4, "test.py", ["--device", "cpu"], _env(tmp_path))
+    assert "all_reduce over pp group -> 1" in out and "all_reduce over pp group -> 5" in out
+    out = _run([sys.executable, "debug.py"], _env(tmp_path))
+    assert "Model parameters: 7978856" in out and "Total num params: 7978856" in out

@@ -1,0 +1,58 @@
+"""HIP kernel numerics vs plain PyTorch fp32 references (run on a real MI355X via gpurun)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from ddl import ops
+    ops.require_ext()                                     # fail loudly: no eager fallback on the GPU path
+    return torch.device("cuda", 0)
+
+
+def test_normalize_u8(dev):
+    from ddl import ops
+    x = torch.randint(0, 256, (5, 3, 37, 41), dtype=torch.uint8, device=dev)
+    ref = x.float() / 255
+    torch.testing.assert_close(ops.normalize_input(x, False), ref)
+    torch.testing.assert_close(ops.normalize_input(x, True), ref.permute(0, 2, 3, 1).contiguous())
+
+
+@pytest.mark.parametrize("B,C", [(30, 5), (7, 5), (1000, 5), (33, 17)])
+def test_fused_cross_entropy(dev, B, C):
+    from ddl import ops
+    g = torch.Generator().manual_seed(B)
+    z = (torch.randn(B, C, generator=g) * 3).to(dev).requires_grad_(True)
+    t = torch.randint(0, C, (B,), generator=g).to(dev)
+    loss, preds = ops.cross_entropy_with_preds(z, t)
+    (loss * 2.0).backward()
+    zr = z.detach().clone().requires_grad_(True)
+    lr = F.cross_entropy(zr, t)
+    (lr * 2.0).backward()
+    torch.testing.assert_close(loss, lr, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(z.grad, zr.grad, rtol=1e-4, atol=1e-7)
+    assert torch.equal(preds, zr.argmax(1))
+
+
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_fused_adam_flat_kernel(dev, wd):
+    from ddl.optim import FusedAdam, _adam_torch
+    from ddl.utils.arena import FlatArena
+    torch.manual_seed(0)
+    params = [("a", torch.nn.Parameter(torch.randn(1000, 33, device=dev))),
+              ("b", torch.nn.Parameter(torch.randn(77, device=dev)))]
+    arena = FlatArena(params)
+    opt = FusedAdam(arena, weight_decay=wd)
+    p_ref, m_ref, v_ref = arena.flat_param.clone().cpu(), opt.exp_avg.clone().cpu(), opt.exp_avg_sq.clone().cpu()
+    for step in range(1, 4):
+        arena.flat_grad.copy_(torch.randn(arena.numel, generator=torch.Generator().manual_seed(step)).to(dev))
+        g_ref = arena.flat_grad.clone().cpu()
+        opt.step(zero_grad=(step == 3))
+        _adam_torch(p_ref, g_ref, m_ref, v_ref, step, 1e-3, 0.9, 0.999, 1e-8, wd, False)
+        torch.testing.assert_close(arena.flat_param.cpu(), p_ref, rtol=2e-5, atol=1e-6)
+        torch.testing.assert_close(opt.exp_avg_sq.cpu(), v_ref, rtol=1e-5, atol=1e-9)
+    assert float(opt.step_t) == 3.0 and arena.flat_grad.abs().sum() == 0      # zero_grad fused in

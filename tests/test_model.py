@@ -1,0 +1,64 @@
+import pytest
+import torch
+
+from ddl.models import densenet as dn
+
+
+def test_param_and_buffer_counts():
+    """6,958,981 params in 364 tensors, 121 BN layers -> 83,769 buffer elements."""
+    m = dn.densenet121(5)
+    assert sum(p.numel() for p in m.parameters()) == 6_958_981
+    assert len(list(m.parameters())) == 364
+    assert sum(b.numel() for b in m.buffers()) == 83_769
+    assert sum(p.numel() for p in dn.densenet121(1000).parameters()) == 7_978_856   # torchvision's count
+
+
+def test_torchvision_key_names():
+    keys = list(dn.densenet121(5).state_dict())
+    for k in ["features.conv0.weight", "features.norm0.running_mean",
+              "features.denseblock1.denselayer1.norm1.weight",
+              "features.denseblock3.denselayer24.conv2.weight", "features.transition2.conv.weight",
+              "features.norm5.num_batches_tracked", "classifier.weight", "classifier.bias"]:
+        assert k in keys
+
+
+def test_reference_two_stage_split():
+    """pp.py:383-385 split -> stage sizes 1,429,632 / 5,529,349, boundary [mb,256,14,14]."""
+    units = dn.stage_units(["features.denseblock3.denselayer1"])
+    sizes = [sum(p.numel() for p in dn.DenseNetStage(u).parameters()) for u in units]
+    assert sizes == [1_429_632, 5_529_349]
+    assert dn.DenseNetStage(units[0]).output_shape((6, 3, 224, 224)) == (6, 256, 14, 14)
+
+
+def test_four_stage_split_partitions_keys():
+    spec = dn.default_split_points(4)
+    full = dn.densenet121(5)
+    seen = []
+    for u in dn.stage_units(spec):
+        seen += list(dn.DenseNetStage(u).state_dict())
+    assert sorted(seen) == sorted(full.state_dict())
+
+
+def test_bad_split_points_rejected():
+    with pytest.raises(ValueError):
+        dn.stage_units(["features.denseblock3.denselayer22"])    # mid-block (reference debug.py:9)
+
+
+def test_stages_compose_to_full_model():
+    torch.manual_seed(0)
+    full = dn.densenet121(5).eval()
+    sd = full.state_dict()
+    x = torch.rand(2, 3, 64, 64)
+    want = full(x)
+    h = x
+    for i in range(4):
+        st = dn.build_stage(i, dn.default_split_points(4), 5, sd).eval()
+        assert st.output_shape(tuple(h.shape)) == tuple(st(h).shape)
+        h = st(h)
+    torch.testing.assert_close(h, want)
+
+
+def test_uint8_input_is_normalised():
+    m = dn.densenet121(5).eval()
+    x = torch.randint(0, 256, (1, 3, 64, 64), dtype=torch.uint8)
+    torch.testing.assert_close(m(x), m(x.float() / 255.0))

@@ -1,0 +1,85 @@
+import copy
+
+import pytest
+import torch
+
+from ddl.optim import FusedAdam
+from ddl.utils.arena import FlatArena, FlatBuffers, reverse_named_parameters
+
+
+def _mlp():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(7, 13), torch.nn.BatchNorm1d(13), torch.nn.ReLU(),
+                               torch.nn.Linear(13, 5))
+
+
+def test_arena_views_alias_params_and_grads():
+    m = _mlp()
+    ref = [p.detach().clone() for p in m.parameters()]
+    a = FlatArena(reverse_named_parameters(m), segment_numel=64, segment_multiple=2 * 64)
+    for p, r in zip(m.parameters(), ref):
+        assert torch.equal(p, r)
+    m(torch.randn(4, 7)).sum().backward()
+    for i, p in enumerate(a.params):
+        assert p.grad.data_ptr() == a.grad_view(i).data_ptr()        # autograd accumulated in place
+    assert a.flat_grad.abs().sum() > 0
+    assert len(a.segments) > 1 and all((s.end - s.start) % 128 == 0 for s in a.segments)
+    assert a.segments[0].start == 0 and a.segments[-1].end == a.numel
+    a.zero_grad()
+    assert all(p.grad.abs().sum() == 0 for p in a.params)
+
+
+def test_flat_buffers_alias():
+    m = _mlp()
+    fb = FlatBuffers(m)
+    m.train()
+    m(torch.randn(8, 7))
+    assert fb.flat_float.abs().sum() > 0 and int(fb.flat_int.sum()) == 1
+
+
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_fused_adam_matches_torch_adam(wd):
+    """Same trajectory as optim.Adam defaults (single.py:108,305) over several steps."""
+    def net():      # no BN: a bias in front of BN has a ~0 gradient, which Adam turns into noise
+        torch.manual_seed(0)
+        return torch.nn.Sequential(torch.nn.Linear(7, 13), torch.nn.Tanh(), torch.nn.Linear(13, 5))
+    m1, m2 = net(), net()
+    o1 = torch.optim.Adam(m1.parameters(), weight_decay=wd)
+    o2 = FusedAdam(FlatArena(reverse_named_parameters(m2)), weight_decay=wd)
+    for step in range(5):
+        x = torch.randn(6, 7, generator=torch.Generator().manual_seed(step))
+        for m, o in ((m1, o1), (m2, o2)):
+            o.zero_grad()
+            m(x).pow(2).mean().backward()
+            o.step()
+    for p1, p2 in zip(m1.parameters(), m2.parameters()):
+        torch.testing.assert_close(p1, p2, rtol=1e-5, atol=1e-7)
+
+
+def test_fused_adam_state_dict_roundtrip_keeps_views():
+    m = _mlp()
+    opt = FusedAdam(FlatArena(reverse_named_parameters(m)))
+    m(torch.randn(4, 7)).sum().backward()
+    opt.step()
+    sd = copy.deepcopy(opt.state_dict())
+    assert set(sd["param_groups"][0]) >= {"lr", "betas", "eps", "weight_decay", "amsgrad", "params"}
+    st0 = sd["state"][0]
+    assert set(st0) == {"step", "exp_avg", "exp_avg_sq"} and float(st0["step"]) == 1.0
+    ptr = opt.exp_avg.data_ptr()
+    opt.exp_avg.zero_()
+    opt.load_state_dict(sd)
+    assert opt.exp_avg.data_ptr() == ptr and opt.exp_avg.abs().sum() > 0
+    assert opt._host_step == 1
+
+
+def test_zero1_shard_updates_only_its_slice():
+    m = _mlp()
+    a = FlatArena(reverse_named_parameters(m), segment_numel=64, segment_multiple=2 * 64)
+    before = a.flat_param.clone()
+    a.flat_grad.fill_(1.0)
+    FusedAdam(a, shard=(1, 2)).step()
+    changed = (a.flat_param != before)
+    for seg in a.segments:
+        half = (seg.end - seg.start) // 2
+        assert not changed[seg.start:seg.start + half].any()
+        assert changed[seg.start + half:seg.end].all()
