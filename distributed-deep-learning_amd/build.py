@@ -80,7 +80,9 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
     def compile_one(job):
         src, flags, obj, stamp_file, stamp = job
-        _run([hipcc, *flags, "-c", str(src), "-o", str(obj)])
+        # .cpp = host-only binding code: plain clang++ (hipcc would add a useless device pass)
+        cc = hipcc if src.suffix == ".hip" else os.environ.get("DDL_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+        _run([cc, *flags, "-c", str(src), "-o", str(obj)])
         stamp_file.write_text(stamp)
         if verbose:
             print(f"[ddl.build] compiled {src.name}", flush=True)

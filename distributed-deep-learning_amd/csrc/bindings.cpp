@@ -2,24 +2,20 @@
 // reset the whole node), then a launch on PyTorch's current HIP stream.  No allocation happens
 // inside the launchers themselves; outputs are allocated here through the caching allocator,
 // which is graph-capture safe.
-#include <torch/extension.h>
-#include <c10/hip/HIPStream.h>
-#include <c10/hip/HIPGuard.h>
-
+#include "torch_hip.h"
 #include "ddl_kernels.h"
 
 namespace {
 
-inline hipStream_t cur_stream() { return c10::hip::getCurrentHIPStream().stream(); }
-
-#define CHECK_DEV(x) TORCH_CHECK((x).is_cuda(), #x " must be a GPU tensor")
-#define CHECK_CONTIG(x) TORCH_CHECK((x).is_contiguous(), #x " must be contiguous")
-#define CHECK_F32(x) TORCH_CHECK((x).scalar_type() == at::kFloat, #x " must be float32")
+using ddl::cur_stream;
+#define CHECK_DEV DDL_CHECK_DEV
+#define CHECK_CONTIG DDL_CHECK_CONTIG
+#define CHECK_F32 DDL_CHECK_F32
 
 at::Tensor normalize_u8(const at::Tensor& x, bool nhwc) {
   CHECK_DEV(x); CHECK_CONTIG(x);
   TORCH_CHECK(x.scalar_type() == at::kByte && x.dim() == 4, "normalize_u8: uint8 [B,C,H,W] expected");
-  c10::hip::HIPGuard guard(x.device());
+  ddl::DeviceGuard guard(x.device());
   const int B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
   auto out = nhwc ? at::empty({B, H, W, C}, x.options().dtype(at::kFloat))
                   : at::empty({B, C, H, W}, x.options().dtype(at::kFloat));
@@ -33,7 +29,7 @@ std::vector<at::Tensor> ce_fwd_bwd(const at::Tensor& logits, const at::Tensor& t
   TORCH_CHECK(logits.dim() == 2 && targets.dim() == 1 && targets.size(0) == logits.size(0),
               "ce_fwd_bwd: logits [B,C], targets [B]");
   TORCH_CHECK(targets.scalar_type() == at::kLong, "targets must be int64");
-  c10::hip::HIPGuard guard(logits.device());
+  ddl::DeviceGuard guard(logits.device());
   const int B = logits.size(0), C = logits.size(1);
   auto loss = at::empty({}, logits.options());
   auto dlogits = at::empty_like(logits);
@@ -46,7 +42,7 @@ std::vector<at::Tensor> ce_fwd_bwd(const at::Tensor& logits, const at::Tensor& t
 void adam_step(at::Tensor p, at::Tensor g, at::Tensor m, at::Tensor v, at::Tensor step_t, at::Tensor aux,
                double lr, double b1, double b2, double eps, double wd, bool zero_grad,
                std::vector<int64_t> starts, std::vector<int64_t> ends) {
-  for (const at::Tensor* t : {&p, &g, &m, &v, &step_t, &aux}) {
+  for (const at::Tensor* t : std::initializer_list<const at::Tensor*>{&p, &g, &m, &v, &step_t, &aux}) {
     CHECK_DEV(*t); CHECK_CONTIG(*t); CHECK_F32(*t);
   }
   const int64_t n = p.numel();
@@ -54,15 +50,14 @@ void adam_step(at::Tensor p, at::Tensor g, at::Tensor m, at::Tensor v, at::Tenso
   TORCH_CHECK(step_t.numel() >= 1 && aux.numel() >= 2, "adam_step: step_t[1], aux[2] expected");
   TORCH_CHECK(starts.size() == ends.size(), "adam_step: ranges");
   TORCH_CHECK((reinterpret_cast<uintptr_t>(p.data_ptr()) % 16) == 0, "arena must be 16-byte aligned");
-  c10::hip::HIPGuard guard(p.device());
+  ddl::DeviceGuard guard(p.device());
   hipStream_t s = cur_stream();
   ddl::launch_adam_inc_step(step_t.data_ptr<float>(), aux.data_ptr<float>(), b1, b2, s);
   for (size_t i = 0; i < starts.size(); ++i) {
     TORCH_CHECK(0 <= starts[i] && starts[i] <= ends[i] && ends[i] <= n, "adam_step: range out of bounds");
     TORCH_CHECK(starts[i] % 4 == 0 && (ends[i] - starts[i]) % 4 == 0, "adam_step: ranges must be float4 aligned");
     ddl::launch_adam_flat(p.data_ptr<float>(), g.data_ptr<float>(), m.data_ptr<float>(), v.data_ptr<float>(),
-                          aux.data_ptr<float>(), starts[i], ends[i], (float)lr, (float)b1, (float)b2,
-                          (float)eps, (float)wd, zero_grad, s);
+                          aux.data_ptr<float>(), starts[i], ends[i], lr, b1, b2, eps, wd, zero_grad, s);
   }
 }
 

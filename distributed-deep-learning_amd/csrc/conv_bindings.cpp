@@ -1,4 +1,227 @@
-// Bindings of the convolution / batch-norm engine kernels (filled in as kernels land).
-#include <torch/extension.h>
+// Bindings of the convolution / batch-norm engine kernels.  Every operand that walks over pixels
+// is passed as a 2-D row-strided view [rows, channels] (stride(1) == 1), e.g. a channel slice of a
+// dense block's NHWC buffer; leading dimensions come from stride(0).  All shape / bounds checks
+// happen here, on the host, before anything is launched.
+#include "torch_hip.h"
+#include "ddl_kernels.h"
 
-void register_conv_ops(pybind11::module_& m) { (void)m; }
+namespace {
+
+using OptT = c10::optional<at::Tensor>;
+using ddl::cur_stream;
+
+void check_rows(const at::Tensor& t, const char* name, int64_t rows, int64_t ch) {
+  TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kFloat, name, ": float32 GPU tensor expected");
+  TORCH_CHECK(t.dim() == 2 && t.stride(1) == 1, name, ": 2-D view with unit channel stride expected");
+  TORCH_CHECK(t.size(0) >= rows && t.size(1) == ch, name, ": expected [>=", rows, ", ", ch, "], got [",
+              t.size(0), ", ", t.size(1), "]");
+  TORCH_CHECK(t.stride(0) % 4 == 0 && (reinterpret_cast<uintptr_t>(t.data_ptr()) % 16) == 0, name,
+              ": rows must be 16-byte aligned (float4 loads)");
+  TORCH_CHECK(ch % 4 == 0, name, ": channel count must be a multiple of 4");
+}
+
+const float* vec_ptr(const OptT& v, const char* name, int64_t n) {
+  if (!v.has_value()) return nullptr;
+  const at::Tensor& t = *v;
+  TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kFloat && t.dim() == 1 && t.stride(0) == 1 &&
+                  t.size(0) >= n, name, ": contiguous float32 vector of >= ", n, " expected");
+  TORCH_CHECK((reinterpret_cast<uintptr_t>(t.data_ptr()) % 16) == 0, name, ": 16-byte alignment required");
+  return t.data_ptr<float>();
+}
+
+ddl::RowSrc make_src(const at::Tensor& x0, const OptT& x1, const OptT& s0, const OptT& s1, const OptT& s2,
+                     bool relu, int64_t rows, int64_t ch, const char* name) {
+  ddl::RowSrc r{};
+  check_rows(x0, name, rows, ch);
+  r.X0 = x0.data_ptr<float>();
+  r.ld0 = (int)x0.stride(0);
+  r.s0 = vec_ptr(s0, "s0", ch);
+  r.s2 = vec_ptr(s2, "s2", ch);
+  TORCH_CHECK((r.s0 == nullptr) == (r.s2 == nullptr), name, ": s0 and s2 come together");
+  if (x1.has_value()) {
+    check_rows(*x1, name, rows, ch);
+    r.X1 = x1->data_ptr<float>();
+    r.ld1 = (int)x1->stride(0);
+    r.s1 = vec_ptr(s1, "s1", ch);
+    TORCH_CHECK(r.s0 != nullptr && r.s1 != nullptr, name, ": a second source needs s0, s1, s2");
+  }
+  r.relu = relu ? 1 : 0;
+  return r;
+}
+
+// out (op)= prologue(x0, x1) (*) weight.  Returns the per-tile statistics table [G,2,N] (or empty).
+at::Tensor conv_gemm(const at::Tensor& x0, const OptT& x1, const OptT& s0, const OptT& s1, const OptT& s2,
+                     bool relu, int64_t M, int64_t H, int64_t W, int64_t taps, bool flip,
+                     const at::Tensor& weight, bool b_kmajor, at::Tensor out, bool ep_mask, bool ep_accum,
+                     const OptT& aux, const OptT& e0, const OptT& e1, int64_t stats_mode, int64_t force_bm) {
+  ddl::DeviceGuard guard(x0.device());
+  const int64_t C = x0.size(1), N = out.size(1);
+  TORCH_CHECK(taps == 1 || taps == 9, "taps must be 1 or 9");
+  TORCH_CHECK(M > 0 && M < (1LL << 31), "bad M");
+  if (taps == 9) {
+    TORCH_CHECK(H > 0 && W > 0 && M % (H * W) == 0, "M must be a whole number of HxW images");
+  }
+  ddl::ConvGemmParams p{};
+  p.a = make_src(x0, x1, s0, s1, s2, relu, M, C, "conv_gemm input");
+  p.M = (int)M; p.C = (int)C; p.N = (int)N; p.H = (int)H; p.W = (int)W; p.taps = (int)taps; p.flip = flip ? 1 : 0;
+  TORCH_CHECK(weight.is_cuda() && weight.scalar_type() == at::kFloat && weight.dim() == 2 &&
+                  weight.stride(1) == 1 && weight.stride(0) % 4 == 0 &&
+                  (reinterpret_cast<uintptr_t>(weight.data_ptr()) % 16) == 0, "weight: 2-D aligned float32 expected");
+  if (!b_kmajor) {
+    TORCH_CHECK(weight.size(0) == N && weight.size(1) == taps * C, "weight must be [N, taps*C]");
+  } else {
+    TORCH_CHECK(weight.size(0) == C && weight.size(1) == taps * N, "k-major weight must be [C, taps*N]");
+  }
+  p.Wt = weight.data_ptr<float>(); p.ldb = (int)weight.stride(0); p.b_kmajor = b_kmajor ? 1 : 0;
+  check_rows(out, "out", M, N);
+  p.out = out.data_ptr<float>(); p.ldo = (int)out.stride(0);
+  p.ep_mask = ep_mask ? 1 : 0; p.ep_accum = ep_accum ? 1 : 0;
+  if (aux.has_value()) { check_rows(*aux, "aux", M, N); p.aux = aux->data_ptr<float>(); p.ldaux = (int)aux->stride(0); }
+  p.e0 = vec_ptr(e0, "e0", N); p.e1 = vec_ptr(e1, "e1", N);
+  if (ep_mask) { TORCH_CHECK(p.aux && p.e0 && p.e1, "ep_mask needs aux, e0, e1"); }
+  if (ep_accum) { TORCH_CHECK(p.e0, "ep_accum needs e0"); }
+  TORCH_CHECK(stats_mode >= 0 && stats_mode <= 2, "stats_mode");
+  if (stats_mode == 2) { TORCH_CHECK(p.aux, "stats_mode 2 needs aux"); }
+  p.stats = (int)stats_mode;
+  at::Tensor stats;
+  if (stats_mode) {
+    const int G = ddl::conv_gemm_grid_x((int)M, (int)N, (int)force_bm);
+    stats = at::empty({G, 2, N}, x0.options());
+    p.stats_out = stats.data_ptr<float>();
+  }
+  ddl::launch_conv_gemm(p, (int)force_bm, cur_stream());
+  return stats;
+}
+
+// dW[N, taps*C] += dO^T * rows(A)
+void conv_wgrad(const at::Tensor& d0, const OptT& d1, const OptT& ds0, const OptT& ds1, const OptT& ds2,
+                const at::Tensor& a0, const OptT& as0, const OptT& as2, bool a_relu, int64_t M, int64_t H,
+                int64_t W, int64_t taps, at::Tensor dW, int64_t min_rows) {
+  ddl::DeviceGuard guard(d0.device());
+  const int64_t N = d0.size(1), C = a0.size(1);
+  TORCH_CHECK(taps == 1 || taps == 9, "taps must be 1 or 9");
+  TORCH_CHECK(M > 0 && M < (1LL << 31), "bad M");
+  ddl::WgradParams p{};
+  p.d = make_src(d0, d1, ds0, ds1, ds2, false, M, N, "wgrad dO");
+  p.a = make_src(a0, c10::nullopt, as0, c10::nullopt, as2, a_relu, M, C, "wgrad activation");
+  p.M = (int)M; p.C = (int)C; p.N = (int)N; p.H = (int)H; p.W = (int)W; p.taps = (int)taps;
+  if (taps == 9) {
+    TORCH_CHECK(N <= 32 && N % 4 == 0, "3x3 wgrad: N <= 32 output channels");
+    TORCH_CHECK(H > 0 && W > 0 && M % (H * W) == 0, "M must be a whole number of HxW images");
+  }
+  TORCH_CHECK(dW.is_cuda() && dW.scalar_type() == at::kFloat && dW.is_contiguous() &&
+                  dW.numel() == N * taps * C && (reinterpret_cast<uintptr_t>(dW.data_ptr()) % 16) == 0,
+              "dW must be a contiguous aligned [N, taps*C] float32 tensor");
+  const int other = taps == 1 ? (int)(((C + 127) / 128) * ((N + 127) / 128)) : (int)(3 * ((C + 127) / 128));
+  p.rows_per_wg = ddl::wgrad_rows_per_wg((int)M, other, (int)min_rows);
+  p.S = (int)((M + p.rows_per_wg - 1) / p.rows_per_wg);
+  auto slabs = at::empty({p.S, N, taps * C}, d0.options());
+  p.slabs = slabs.data_ptr<float>();
+  ddl::launch_wgrad(p, dW.data_ptr<float>(), cur_stream());
+}
+
+void bn_prep(const OptT& partials, int64_t new0, int64_t n_new, double count, at::Tensor chan_mean,
+             at::Tensor chan_var, at::Tensor chan_rstd, const OptT& gamma, const OptT& beta, const OptT& run_mean,
+             const OptT& run_var, const OptT& scale, const OptT& shift, int64_t C, double momentum, double eps,
+             bool train) {
+  ddl::DeviceGuard guard(chan_mean.device());
+  int G = 0, ldp = 0;
+  const float* pp = nullptr;
+  if (partials.has_value()) {
+    const at::Tensor& t = *partials;
+    TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kFloat && t.is_contiguous() && t.dim() == 3 && t.size(1) == 2,
+                "partials: [G,2,n] expected");
+    TORCH_CHECK(t.size(2) >= n_new && n_new % 32 == 0 && new0 % 32 == 0, "new channel range must be 32-aligned");
+    G = (int)t.size(0); ldp = (int)t.size(2); pp = t.data_ptr<float>();
+  }
+  TORCH_CHECK(C % 32 == 0, "bn_prep: C must be a multiple of 32");
+  for (const at::Tensor* t : std::initializer_list<const at::Tensor*>{&chan_mean, &chan_var, &chan_rstd})
+    TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kFloat && t->is_contiguous() && t->numel() >= C &&
+                    t->numel() >= new0 + n_new, "channel stat table too small");
+  const float* g = vec_ptr(gamma, "gamma", C);
+  TORCH_CHECK(!train || count > 0, "count");
+  float* rm = run_mean.has_value() ? run_mean->data_ptr<float>() : nullptr;
+  float* rv = run_var.has_value() ? run_var->data_ptr<float>() : nullptr;
+  if (run_mean.has_value()) { TORCH_CHECK(run_mean->numel() >= C && run_var.has_value() && run_var->numel() >= C, "running stats"); }
+  if (!train && g != nullptr) { TORCH_CHECK(rm && rv, "eval mode needs running stats"); }
+  float* sc = scale.has_value() ? scale->data_ptr<float>() : nullptr;
+  float* sh = shift.has_value() ? shift->data_ptr<float>() : nullptr;
+  if (g != nullptr) { TORCH_CHECK(sc && sh && scale->numel() >= C && shift->numel() >= C && vec_ptr(beta, "beta", C), "scale/shift/beta"); }
+  ddl::launch_bn_prep(pp, G, ldp, (int)new0, (int)n_new, count, chan_mean.data_ptr<float>(),
+                      chan_var.data_ptr<float>(), chan_rstd.data_ptr<float>(), g, vec_ptr(beta, "beta", g ? C : 0), rm, rv,
+                      sc, sh, (int)C, (float)momentum, (float)eps, train, cur_stream());
+}
+
+void bn_bwd_prep(const at::Tensor& partials, double count, const at::Tensor& chan_mean, const at::Tensor& chan_rstd,
+                 const at::Tensor& scale, at::Tensor dgamma, at::Tensor dbeta, const OptT& k0, at::Tensor k1,
+                 at::Tensor k2, int64_t C, int64_t mode) {
+  ddl::DeviceGuard guard(partials.device());
+  TORCH_CHECK(partials.is_cuda() && partials.scalar_type() == at::kFloat && partials.is_contiguous() &&
+                  partials.dim() == 3 && partials.size(1) == 2 && partials.size(2) >= C, "partials: [G,2,>=C]");
+  TORCH_CHECK(C % 32 == 0, "C must be a multiple of 32");
+  for (const at::Tensor* t : std::initializer_list<const at::Tensor*>{&chan_mean, &chan_rstd, &scale, &dgamma, &dbeta, &k1, &k2})
+    TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kFloat && t->stride(-1) == 1 && t->numel() >= C, "vector too small");
+  float* k0p = nullptr;
+  if (mode == 0) { TORCH_CHECK(k0.has_value() && k0->numel() >= C, "mode 0 needs k0"); k0p = k0->data_ptr<float>(); }
+  ddl::launch_bn_bwd_prep(partials.data_ptr<float>(), (int)partials.size(0), (int)partials.size(2), count,
+                          chan_mean.data_ptr<float>(), chan_rstd.data_ptr<float>(), scale.data_ptr<float>(),
+                          dgamma.data_ptr<float>(), dbeta.data_ptr<float>(), k0p, k1.data_ptr<float>(),
+                          k2.data_ptr<float>(), (int)C, (int)mode, cur_stream());
+}
+
+// pixel glue ops (see bn_kernels.hip rows_op); returns the statistics table or an empty tensor
+at::Tensor rows_op(int64_t mode, int64_t M, const at::Tensor& in, const OptT& x, const OptT& sc, const OptT& sh,
+                   at::Tensor out, int64_t H, int64_t W, bool want_stats) {
+  ddl::DeviceGuard guard(in.device());
+  const int64_t C = out.size(1);
+  TORCH_CHECK(mode >= 0 && mode <= 4, "rows_op mode");
+  TORCH_CHECK(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, "rows_op: C must be 4*2^k <= 1024");
+  check_rows(out, "out", M, C);
+  int64_t in_rows = M;
+  if (mode == 1) { TORCH_CHECK(H % 2 == 0 && W % 2 == 0 && M % ((H / 2) * (W / 2)) == 0, "pool fwd geometry"); in_rows = 0; }
+  if (mode == 2) { TORCH_CHECK(H % 2 == 0 && W % 2 == 0 && M % (H * W) == 0, "pool bwd geometry"); in_rows = M / 4; }
+  if (mode == 3) { TORCH_CHECK(H > 0 && W > 0 && M % (H * W) == 0, "gap bwd geometry"); in_rows = M / (H * W); }
+  const float* inp = nullptr; int ldi = 0;
+  if (mode != 1) { check_rows(in, "in", in_rows, C); inp = in.data_ptr<float>(); ldi = (int)in.stride(0); }
+  const float* xp = nullptr; int ldx = 0;
+  if (mode != 0) {
+    TORCH_CHECK(x.has_value(), "rows_op: x required");
+    check_rows(*x, "x", mode == 1 ? M * 4 : M, C);
+    xp = x->data_ptr<float>(); ldx = (int)x->stride(0);
+    TORCH_CHECK(sc.has_value() && sh.has_value(), "rows_op: sc/sh required");
+  }
+  const float* scp = vec_ptr(sc, "sc", C);
+  const float* shp = vec_ptr(sh, "sh", C);
+  at::Tensor stats;
+  float* sp = nullptr;
+  if (want_stats) {
+    TORCH_CHECK(mode == 0 || mode == 2 || mode == 3, "stats only for copy / backward modes");
+    stats = at::empty({ddl::rows_op_grid(M, (int)C), 2, C}, out.options());
+    sp = stats.data_ptr<float>();
+  }
+  ddl::launch_rows_op((int)mode, M, (int)C, inp, ldi, xp, ldx, scp, shp, out.data_ptr<float>(), (int)out.stride(0),
+                      (int)H, (int)W, sp, cur_stream());
+  return stats;
+}
+
+at::Tensor bnrelu_gap_fwd(const at::Tensor& x, int64_t B, int64_t HW, const at::Tensor& sc, const at::Tensor& sh) {
+  ddl::DeviceGuard guard(x.device());
+  const int64_t C = x.size(1);
+  check_rows(x, "x", B * HW, C);
+  TORCH_CHECK(sc.numel() >= C && sh.numel() >= C && sc.is_cuda() && sh.is_cuda(), "sc/sh");
+  auto pooled = at::empty({B, C}, x.options().memory_format(at::MemoryFormat::Contiguous));
+  ddl::launch_bnrelu_gap_fwd(x.data_ptr<float>(), (int)x.stride(0), (int)B, (int)HW, sc.data_ptr<float>(),
+                             sh.data_ptr<float>(), pooled.data_ptr<float>(), (int)C, cur_stream());
+  return pooled;
+}
+
+}  // namespace
+
+void register_conv_ops(pybind11::module_& m) {
+  m.def("conv_gemm", &conv_gemm, "implicit-GEMM conv (1x1 / 3x3) with fused prologue + epilogue");
+  m.def("conv_wgrad", &conv_wgrad, "conv weight gradient (split-M slabs + deterministic reduce)");
+  m.def("bn_prep", &bn_prep, "finalize channel statistics, derive BN scale/shift, update running stats");
+  m.def("bn_bwd_prep", &bn_bwd_prep, "BN backward per-channel coefficients, dgamma/dbeta");
+  m.def("rows_op", &rows_op, "pixel glue ops (copy+stats, pool fwd/bwd, gap bwd, deferred-term apply)");
+  m.def("bnrelu_gap_fwd", &bnrelu_gap_fwd, "BN+ReLU+global average pool");
+}

@@ -1,0 +1,62 @@
+// Parameter blocks of the implicit-GEMM convolution kernels (NHWC, fp32, gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace ddl {
+
+// "Row source": the GEMM operand that walks over pixels (rows m = (b, y, x) of an NHWC tensor).
+// Element (m, c) = s0[c] * X0[m*ld0 + c] + s1[c] * X1[m*ld1 + c] + s2[c], then optional ReLU.
+//   s0 == nullptr -> plain X0 (identity);  X1 == nullptr -> single source.
+// This one form covers: BN+ReLU of the forward pass (s0 = gamma*rstd, s2 = beta - mean*s0),
+// the BN-backward correction dh = k0*g + k1*h + k2, and the deferred dense-block gradient
+// dY = dBuf - Q*x - P  (see models/native_densenet.py).
+struct RowSrc {
+  const float* X0;
+  const float* X1;
+  const float* s0;
+  const float* s1;
+  const float* s2;
+  int ld0;
+  int ld1;
+  int relu;
+};
+
+// out[M x N] (op)= rows(A)[M x taps*C] * W
+struct ConvGemmParams {
+  RowSrc a;
+  int M, C, N;        // pixels, channels per tap of the row source (GEMM K = taps*C), output channels
+  int H, W;           // spatial size (3x3 taps only)
+  int taps;           // 1 or 9 (3x3, stride 1, pad 1)
+  int flip;           // 1: tap offsets negated (data-gradient of a 3x3 conv)
+  // weights: n-major  W[n*ldb + tap*C + c]      (forward: layout [N][taps][C])
+  //          k-major  W[c*ldb + tap*N + n]      (dgrad: the same forward tensor read transposed)
+  const float* Wt;
+  int ldb;
+  int b_kmajor;
+  // epilogue
+  float* out;
+  int ldo;            // row stride of out (channel-slice writes into a block buffer: ldo > N)
+  int ep_mask;        // 1: g = (e0[n]*aux[m][n] + e1[n] > 0) ? acc : 0   (ReLU backward through BN)
+  int ep_accum;       // 1: out += e0[n] * g  (BN1 backward into the shared dBuf);  0: out = g
+  const float* aux;
+  int ldaux;
+  const float* e0;
+  const float* e1;
+  int stats;          // 0 none; 1: per-column sum(v), sum(v*v); 2: sum(g), sum(g*aux)
+  float* stats_out;   // [gridDim.x][2][N]
+};
+
+// dW[N x taps*C] += dO^T[N x M] * rows(A)[M x taps*C]   (weight gradient; split over M, slab output)
+struct WgradParams {
+  RowSrc d;           // dO source, N channels
+  RowSrc a;           // activation source, C channels
+  int M, C, N;
+  int H, W;
+  int taps;           // 1 or 9
+  int rows_per_wg;    // multiple of 32
+  float* slabs;       // [S][N][taps*C]  partial sums, one slab per M-chunk
+  int S;
+};
+
+}  // namespace ddl

@@ -18,7 +18,32 @@ void launch_ce_fwd_bwd(const float* logits, const int64_t* targets, float* loss 
 void launch_adam_inc_step(float* step_t, float* aux /*[2]: 1-b1^t, 1/sqrt(1-b2^t)*/, double b1, double b2,
                           hipStream_t s);
 void launch_adam_flat(float* p, float* g, float* m, float* v, const float* aux, int64_t start,
-                      int64_t end, float lr, float b1, float b2, float eps, float wd, bool zero_grad,
+                      int64_t end, double lr, double b1, double b2, double eps, double wd, bool zero_grad,
                       hipStream_t s);
 
+}  // namespace ddl
+
+#include "conv_params.h"
+
+namespace ddl {
+// ---- conv_gemm.hip ---------------------------------------------------------------------
+int conv_gemm_grid_x(int M, int N, int force_bm);   // number of row tiles (= rows of the stats table)
+void launch_conv_gemm(const ConvGemmParams& p, int force_bm, hipStream_t s);
+// ---- conv_wgrad.hip --------------------------------------------------------------------
+int wgrad_rows_per_wg(int M, int other_grid, int min_rows);
+void launch_wgrad(const WgradParams& p, float* dW, hipStream_t s);
+// ---- bn_kernels.hip --------------------------------------------------------------------
+void launch_bn_prep(const float* partials, int G, int ldp, int new0, int n_new, double count,
+                    float* chan_mean, float* chan_var, float* chan_rstd, const float* gamma,
+                    const float* beta, float* run_mean, float* run_var, float* scale, float* shift,
+                    int C, float momentum, float eps, bool train, hipStream_t s);
+void launch_bn_bwd_prep(const float* partials, int G, int ldp, double count, const float* chan_mean,
+                        const float* chan_rstd, const float* scale, float* dgamma, float* dbeta, float* k0,
+                        float* k1, float* k2, int C, int mode, hipStream_t s);
+int rows_op_grid(long M, int C);
+int launch_rows_op(int mode, long M, int C, const float* in, int ldi, const float* x, int ldx,
+                   const float* sc, const float* sh, float* out, int ldo, int H, int W, float* stats,
+                   hipStream_t s);
+void launch_bnrelu_gap_fwd(const float* x, int ldx, int B, int HW, const float* sc, const float* sh,
+                           float* pooled, int C, hipStream_t s);
 }  // namespace ddl

@@ -110,12 +110,14 @@ void launch_adam_inc_step(float* step_t, float* aux, double b1, double b2, hipSt
   hipLaunchKernelGGL(adam_inc_step_kernel, dim3(1), dim3(64), 0, s, step_t, aux, b1, b2);
 }
 
+// omb1/omb2 = (1 - beta) rounded from double on the host (1.f - 0.999f is off by 5e-5 relative)
 __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v, float lr_c, float b1,
-                                         float b2, float eps, float wd, float inv_sqrt_bc2) {
+                                         float b2, float omb1, float omb2, float eps, float wd,
+                                         float inv_sqrt_bc2) {
   float gg = g;
   if (wd != 0.f) gg += wd * p;
-  m = b1 * m + (1.f - b1) * gg;
-  v = b2 * v + (1.f - b2) * gg * gg;
+  m = b1 * m + omb1 * gg;
+  v = b2 * v + omb2 * gg * gg;
   float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
   p -= lr_c * (m / denom);
 }
@@ -123,8 +125,9 @@ __device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v,
 __global__ void __launch_bounds__(256) adam_flat_kernel(float* __restrict__ p, float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         const float* __restrict__ aux, long n4,
-                                                        float lr, float b1, float b2, float eps,
-                                                        float wd, bool zero_grad) {
+                                                        float lr, float b1, float b2, float omb1,
+                                                        float omb2, float eps, float wd,
+                                                        bool zero_grad) {
   const float lr_c = lr / aux[0];
   const float inv_sqrt_bc2 = aux[1];
   float4* p4 = reinterpret_cast<float4*>(p);
@@ -133,10 +136,10 @@ __global__ void __launch_bounds__(256) adam_flat_kernel(float* __restrict__ p, f
   float4* v4 = reinterpret_cast<float4*>(v);
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
     float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
-    adam_one(pp.x, gg.x, mm.x, vv.x, lr_c, b1, b2, eps, wd, inv_sqrt_bc2);
-    adam_one(pp.y, gg.y, mm.y, vv.y, lr_c, b1, b2, eps, wd, inv_sqrt_bc2);
-    adam_one(pp.z, gg.z, mm.z, vv.z, lr_c, b1, b2, eps, wd, inv_sqrt_bc2);
-    adam_one(pp.w, gg.w, mm.w, vv.w, lr_c, b1, b2, eps, wd, inv_sqrt_bc2);
+    adam_one(pp.x, gg.x, mm.x, vv.x, lr_c, b1, b2, omb1, omb2, eps, wd, inv_sqrt_bc2);
+    adam_one(pp.y, gg.y, mm.y, vv.y, lr_c, b1, b2, omb1, omb2, eps, wd, inv_sqrt_bc2);
+    adam_one(pp.z, gg.z, mm.z, vv.z, lr_c, b1, b2, omb1, omb2, eps, wd, inv_sqrt_bc2);
+    adam_one(pp.w, gg.w, mm.w, vv.w, lr_c, b1, b2, omb1, omb2, eps, wd, inv_sqrt_bc2);
     p4[i] = pp;
     m4[i] = mm;
     v4[i] = vv;
@@ -145,7 +148,7 @@ __global__ void __launch_bounds__(256) adam_flat_kernel(float* __restrict__ p, f
 }
 
 void launch_adam_flat(float* p, float* g, float* m, float* v, const float* aux, int64_t start,
-                      int64_t end, float lr, float b1, float b2, float eps, float wd, bool zero_grad,
+                      int64_t end, double lr, double b1, double b2, double eps, double wd, bool zero_grad,
                       hipStream_t s) {
   // arena ranges are multiples of 64 elements (FlatArena alignment) -> float4-safe
   long n4 = (long)(end - start) / 4;
@@ -153,7 +156,8 @@ void launch_adam_flat(float* p, float* g, float* m, float* v, const float* aux, 
   long grid = (n4 + 255) / 256;
   if (grid > 256 * 8) grid = 256 * 8;
   hipLaunchKernelGGL(adam_flat_kernel, dim3((int)grid), dim3(256), 0, s, p + start, g + start, m + start,
-                     v + start, aux, n4, lr, b1, b2, eps, wd, zero_grad);
+                     v + start, aux, n4, (float)lr, (float)b1, (float)b2, (float)(1.0 - b1), (float)(1.0 - b2),
+                     (float)eps, (float)wd, zero_grad);
 }
 
 }  // namespace ddl

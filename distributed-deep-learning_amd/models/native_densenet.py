@@ -1,0 +1,483 @@
+"""DenseNet-121 on hand-written gfx950 kernels: the MI355X-native engine.
+
+Same architecture, parameter names and numerics (fp32) as ``ddl.models.densenet`` /
+``torchvision.models.densenet121`` (reference: single.py:297-299), executed very differently:
+
+  layout      NHWC; a dense block owns ONE pre-allocated buffer ``[B,H,W,C_final]``.  Layer i
+              reads the channel prefix ``[:C_i]`` and its 3x3 conv writes channels
+              ``[C_i:C_i+32]`` in place - ``torch.cat`` (O(L^2) copies) does not exist.
+  BN          batch statistics of a channel are computed once, in the epilogue of the conv that
+              produced it, and shared by all later ``norm1`` layers of the block (they normalise
+              the same data); each layer only derives ``scale = gamma*rstd, shift = beta-mean*scale``.
+              BN+ReLU is applied while the following conv stages its A operand: the normalised
+              tensor never exists in HBM (SURVEY K3 "best fused as prologue of the 1x1 conv").
+  convs       fp32 MFMA implicit GEMM (csrc/conv_gemm.hip, conv_wgrad.hip).
+  backward    hand-derived.  ``dBuf`` (gradient of the block buffer) is accumulated in place by
+              the 1x1 data-gradient epilogue (ReLU mask, BN scale, per-channel sums fused).  The
+              two "mean-subtraction" terms of every BN backward are per-channel affine functions
+              of the buffer itself, so they are *deferred*: accumulated as two vectors (NQ, NP)
+              and applied on the fly when a channel slice is finally consumed
+              (``dY = dBuf + NQ*x + NP`` in the 3x3 kernels' operand prologue).  Per layer the wide
+              prefix is touched 3 times (mask read, dBuf read-modify-write) instead of 5+.
+  params      one flat arena (``FlatArena``): gradients are written straight into it (no
+              per-parameter autograd accumulation kernels); it doubles as the DP bucket space.
+  units       every unit (stem, block, transition, head-pool) is ONE autograd node, so pipeline
+              stages and the data-parallel reducer see ~10 nodes instead of ~600.
+
+The stem (7x7 conv + BN + ReLU + max-pool, 4% of the FLOPs) and the 1024->5 classifier GEMM
+still go through PyTorch-ROCm library ops (MIOpen / rocBLAS); everything else is native.
+
+Weight layouts (converted at the checkpoint boundary by ``ddl_export_tensor`` /
+``ddl_import_tensor``, so checkpoints stay in the torchvision layout - SURVEY 5.4):
+  1x1 conv  [N, C]           (= torch [N, C, 1, 1])
+  3x3 conv  [N, 9*C] (tap-major, channel-minor = torch.permute(0, 2, 3, 1))
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..utils.arena import FlatArena, FlatBuffers, reverse_named_parameters
+from .densenet import (BLOCK_CONFIG, BN_SIZE, GROWTH, UNIT_NAMES, DenseNetStage, block_channels)
+
+BN_MOMENTUM = 0.1
+BN_EPS = 1e-5
+MID = BN_SIZE * GROWTH      # 128 bottleneck channels
+
+
+def _ext():
+    return ops.require_ext()
+
+
+# ======================================================================================
+# dense block
+# ======================================================================================
+class _BlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_in: torch.Tensor, anchor: torch.Tensor, unit: "BlockUnit"):
+        ext = _ext()
+        train = unit.stage.training
+        B, H, W, C0 = x_in.shape
+        L, Cf = unit.num_layers, unit.c_out
+        M = B * H * W
+        dev = x_in.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        buf = torch.empty(B, H, W, Cf, **f32)
+        buf2d = buf.view(M, Cf)
+        stats = torch.empty(3, Cf, **f32)                   # chan_mean / chan_var / chan_rstd
+        sc1 = torch.empty(L, Cf, **f32)
+        sh1 = torch.empty(L, Cf, **f32)
+        bn2 = torch.empty(L, 5, MID, **f32)                 # mean2, var2, rstd2, sc2, sh2
+        h = torch.empty(L, M, MID, **f32)                   # bottleneck activations (pre-BN2)
+        x2d = x_in.reshape(M, C0)
+        part = ext.rows_op(0, M, x2d, None, None, None, buf2d[:, :C0], H, W, train)
+        new0, n_new = 0, C0
+        for l, lay in enumerate(unit.layers):
+            C = C0 + GROWTH * l
+            ext.bn_prep(part if train else None, new0, n_new, float(M), stats[0], stats[1], stats[2],
+                        lay.g1, lay.b1, lay.rm1, lay.rv1, sc1[l], sh1[l], C, BN_MOMENTUM, BN_EPS, train)
+            st = ext.conv_gemm(buf2d[:, :C], None, sc1[l], None, sh1[l], True, M, H, W, 1, False,
+                               lay.w1, False, h[l], False, False, None, None, None, 1 if train else 0, 0)
+            ext.bn_prep(st if train else None, 0, MID, float(M), bn2[l, 0], bn2[l, 1], bn2[l, 2],
+                        lay.g2, lay.b2, lay.rm2, lay.rv2, bn2[l, 3], bn2[l, 4], MID, BN_MOMENTUM, BN_EPS, train)
+            part = ext.conv_gemm(h[l], None, bn2[l, 3], None, bn2[l, 4], True, M, H, W, 9, False,
+                                 lay.w2, False, buf2d[:, C:C + GROWTH], False, False, None, None, None,
+                                 1 if train else 0, 0)
+            new0, n_new = C, GROWTH
+        if train:   # statistics of the last slice (consumed by the following transition / head)
+            ext.bn_prep(part, new0, n_new, float(M), stats[0], stats[1], stats[2], None, None, None, None,
+                        None, None, Cf, BN_MOMENTUM, BN_EPS, True)
+        unit.out_stats = stats if train else None
+        ctx.unit = unit
+        ctx.geom = (B, H, W, C0)
+        ctx.save_for_backward(buf, stats, sc1, sh1, bn2, h)
+        return buf
+
+    @staticmethod
+    def backward(ctx, dbuf: torch.Tensor):
+        ext = _ext()
+        unit = ctx.unit
+        buf, stats, sc1, sh1, bn2, h = ctx.saved_tensors
+        B, H, W, C0 = ctx.geom
+        L, Cf = unit.num_layers, unit.c_out
+        M = B * H * W
+        f32 = dict(dtype=torch.float32, device=buf.device)
+        dbuf = dbuf.contiguous()
+        d2d = dbuf.view(M, Cf)
+        buf2d = buf.view(M, Cf)
+        nq = torch.zeros(Cf, **f32)           # deferred terms: dX = dBuf + nq * x + np
+        np_ = torch.zeros(Cf, **f32)
+        ones = unit.stage.ones
+        k = torch.empty(3, MID, **f32)
+        g2 = torch.empty(M, MID, **f32)
+        for l in range(L - 1, -1, -1):
+            lay = unit.layers[l]
+            C = C0 + GROWTH * l
+            sl = slice(C, C + GROWTH)
+            dy, xs = d2d[:, sl], buf2d[:, sl]
+            sc2, sh2 = bn2[l, 3], bn2[l, 4]
+            # 3x3 data gradient (+ ReLU/BN2 mask, sum g2, sum g2*h)
+            st = ext.conv_gemm(dy, xs, ones[:GROWTH], nq[sl], np_[sl], False, M, H, W, 9, True,
+                               lay.w2, True, g2, True, False, h[l], sc2, sh2, 2, 0)
+            # 3x3 weight gradient
+            ext.conv_wgrad(dy, xs, ones[:GROWTH], nq[sl], np_[sl], h[l], sc2, sh2, True, M, H, W, 9,
+                           lay.gw2, unit.stage.wgrad_min_rows)
+            ext.bn_bwd_prep(st, float(M), bn2[l, 0], bn2[l, 2], sc2, lay.gg2, lay.gb2, k[0], k[1], k[2], MID, 0)
+            # 1x1 data gradient: dh = k0*g2 + k1*h + k2 on the fly; epilogue: mask, dBuf += sc1*g1, sums
+            st1 = ext.conv_gemm(g2, h[l], k[0], k[1], k[2], False, M, H, W, 1, False,
+                                lay.w1, True, d2d[:, :C], True, True, buf2d[:, :C], sc1[l], sh1[l], 2, 0)
+            # 1x1 weight gradient (activation re-normalised on the fly)
+            ext.conv_wgrad(g2, h[l], k[0], k[1], k[2], buf2d[:, :C], sc1[l], sh1[l], True, M, H, W, 1,
+                           lay.gw1, unit.stage.wgrad_min_rows)
+            ext.bn_bwd_prep(st1, float(M), stats[0], stats[2], sc1[l], lay.gg1, lay.gb1, None, nq, np_, C, 1)
+        dx = torch.empty(B, H, W, C0, **f32)
+        ext.rows_op(4, M, d2d[:, :C0], buf2d[:, :C0], nq, np_, dx.view(M, C0), H, W, False)
+        unit.stage._unit_grads_ready(unit)
+        return dx, None, None
+
+
+class _Layer:
+    """Parameter / gradient views of one dense layer (all views into the flat arena)."""
+    __slots__ = ("g1", "b1", "rm1", "rv1", "w1", "g2", "b2", "rm2", "rv2", "w2",
+                 "gg1", "gb1", "gw1", "gg2", "gb2", "gw2")
+
+
+class BlockUnit:
+    def __init__(self, stage: "NativeDenseNetStage", name: str) -> None:
+        self.stage, self.name = stage, name
+        b = int(name[-1]) - 1
+        self.num_layers = BLOCK_CONFIG[b]
+        self.c_in, self.c_out = block_channels()[b]
+        self.layers: List[_Layer] = []
+        self.out_stats: Optional[torch.Tensor] = None
+        self.param_names: List[str] = []
+
+    def bind(self) -> None:
+        st = self.stage
+        self.layers = []
+        for i in range(self.num_layers):
+            pre = f"features.{self.name}.denselayer{i + 1}."
+            lay = _Layer()
+            lay.g1, lay.gg1 = st.pv(pre + "norm1.weight")
+            lay.b1, lay.gb1 = st.pv(pre + "norm1.bias")
+            lay.w1, lay.gw1 = st.pv(pre + "conv1.weight")
+            lay.g2, lay.gg2 = st.pv(pre + "norm2.weight")
+            lay.b2, lay.gb2 = st.pv(pre + "norm2.bias")
+            lay.w2, lay.gw2 = st.pv(pre + "conv2.weight")
+            lay.rm1, lay.rv1 = st.bv(pre + "norm1.running_mean"), st.bv(pre + "norm1.running_var")
+            lay.rm2, lay.rv2 = st.bv(pre + "norm2.running_mean"), st.bv(pre + "norm2.running_var")
+            self.layers.append(lay)
+        self.param_names = [n for n in st.param_index if n.startswith(f"features.{self.name}.")]
+
+    def __call__(self, x: torch.Tensor, in_stats) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        y = _BlockFn.apply(x, self.stage.anchor, self)
+        return y, self.out_stats
+
+
+# ======================================================================================
+# transition: BN+ReLU -> 2x2 avg-pool -> 1x1 conv  (pool and 1x1 conv commute: 4x fewer GEMM rows)
+# ======================================================================================
+def _input_stats(ext, buf2d: torch.Tensor, M: int, C: int, H: int, W: int) -> torch.Tensor:
+    """Channel statistics of a tensor that did not come with any (a stage that starts here)."""
+    stats = torch.empty(3, C, dtype=torch.float32, device=buf2d.device)
+    scratch = torch.empty(M, C, dtype=torch.float32, device=buf2d.device)
+    part = ext.rows_op(0, M, buf2d, None, None, None, scratch, H, W, True)
+    ext.bn_prep(part, 0, C, float(M), stats[0], stats[1], stats[2], None, None, None, None, None, None, C,
+                BN_MOMENTUM, BN_EPS, True)
+    return stats
+
+
+class _TransitionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, buf: torch.Tensor, anchor: torch.Tensor, unit: "TransitionUnit", in_stats):
+        ext = _ext()
+        train = unit.stage.training
+        B, H, W, C = buf.shape
+        M, Mp, Co = B * H * W, B * (H // 2) * (W // 2), C // 2
+        f32 = dict(dtype=torch.float32, device=buf.device)
+        buf = buf.contiguous()
+        buf2d = buf.view(M, C)
+        if train and in_stats is None:
+            in_stats = _input_stats(ext, buf2d, M, C, H, W)
+        stats = in_stats if train else torch.empty(3, C, **f32)
+        ss = torch.empty(2, C, **f32)
+        ext.bn_prep(None, 0, 0, float(M), stats[0], stats[1], stats[2], unit.g, unit.b, unit.rm, unit.rv,
+                    ss[0], ss[1], C, BN_MOMENTUM, BN_EPS, train)
+        pooled = torch.empty(Mp, C, **f32)
+        ext.rows_op(1, Mp, pooled, buf2d, ss[0], ss[1], pooled, H, W, False)
+        y = torch.empty(B, H // 2, W // 2, Co, **f32)
+        ext.conv_gemm(pooled, None, None, None, None, False, Mp, H // 2, W // 2, 1, False, unit.w, False,
+                      y.view(Mp, Co), False, False, None, None, None, 0, 0)
+        ctx.unit = unit
+        ctx.geom = (B, H, W, C)
+        ctx.save_for_backward(buf, stats, ss, pooled)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: torch.Tensor):
+        ext = _ext()
+        unit = ctx.unit
+        buf, stats, ss, pooled = ctx.saved_tensors
+        B, H, W, C = ctx.geom
+        M, Mp, Co = B * H * W, B * (H // 2) * (W // 2), C // 2
+        f32 = dict(dtype=torch.float32, device=buf.device)
+        dy2d = dy.contiguous().view(Mp, Co)
+        buf2d = buf.view(M, C)
+        ext.conv_wgrad(dy2d, None, None, None, None, pooled, None, None, False, Mp, H // 2, W // 2, 1,
+                       unit.gw, unit.stage.wgrad_min_rows)
+        dpool = torch.empty(Mp, C, **f32)
+        ext.conv_gemm(dy2d, None, None, None, None, False, Mp, H // 2, W // 2, 1, False, unit.w, True,
+                      dpool, False, False, None, None, None, 0, 0)
+        dbuf = torch.empty(B, H, W, C, **f32)
+        d2d = dbuf.view(M, C)
+        st = ext.rows_op(2, M, dpool, buf2d, ss[0], ss[1], d2d, H, W, True)
+        k = torch.empty(3, C, **f32)
+        ext.bn_bwd_prep(st, float(M), stats[0], stats[2], ss[0], unit.gg, unit.gb, k[0], k[1], k[2], C, 0)
+        ext.rows_op(4, M, d2d, buf2d, k[1], k[2], d2d, H, W, False)     # dX = sc*g + k1*x + k2
+        unit.stage._unit_grads_ready(unit)
+        return dbuf, None, None, None
+
+
+class TransitionUnit:
+    def __init__(self, stage: "NativeDenseNetStage", name: str) -> None:
+        self.stage, self.name = stage, name
+        self.param_names: List[str] = []
+
+    def bind(self) -> None:
+        st, pre = self.stage, f"features.{self.name}."
+        self.g, self.gg = st.pv(pre + "norm.weight")
+        self.b, self.gb = st.pv(pre + "norm.bias")
+        self.w, self.gw = st.pv(pre + "conv.weight")
+        self.rm, self.rv = st.bv(pre + "norm.running_mean"), st.bv(pre + "norm.running_var")
+        self.param_names = [n for n in st.param_index if n.startswith(pre)]
+
+    def __call__(self, x, in_stats):
+        return _TransitionFn.apply(x, self.stage.anchor, self, in_stats), None
+
+
+# ======================================================================================
+# head: norm5 + ReLU + global average pool (native) -> Linear (rocBLAS via torch)
+# ======================================================================================
+class _HeadPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, buf: torch.Tensor, anchor: torch.Tensor, unit: "HeadUnit", in_stats):
+        ext = _ext()
+        train = unit.stage.training
+        B, H, W, C = buf.shape
+        M = B * H * W
+        f32 = dict(dtype=torch.float32, device=buf.device)
+        buf = buf.contiguous()
+        buf2d = buf.view(M, C)
+        if train and in_stats is None:
+            in_stats = _input_stats(ext, buf2d, M, C, H, W)
+        stats = in_stats if train else torch.empty(3, C, **f32)
+        ss = torch.empty(2, C, **f32)
+        ext.bn_prep(None, 0, 0, float(M), stats[0], stats[1], stats[2], unit.g, unit.b, unit.rm, unit.rv,
+                    ss[0], ss[1], C, BN_MOMENTUM, BN_EPS, train)
+        pooled = ext.bnrelu_gap_fwd(buf2d, B, H * W, ss[0], ss[1])
+        ctx.unit = unit
+        ctx.geom = (B, H, W, C)
+        ctx.save_for_backward(buf, stats, ss)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled: torch.Tensor):
+        ext = _ext()
+        unit = ctx.unit
+        buf, stats, ss = ctx.saved_tensors
+        B, H, W, C = ctx.geom
+        M = B * H * W
+        f32 = dict(dtype=torch.float32, device=buf.device)
+        buf2d = buf.view(M, C)
+        dbuf = torch.empty(B, H, W, C, **f32)
+        d2d = dbuf.view(M, C)
+        st = ext.rows_op(3, M, dpooled.contiguous(), buf2d, ss[0], ss[1], d2d, H, W, True)
+        k = torch.empty(3, C, **f32)
+        ext.bn_bwd_prep(st, float(M), stats[0], stats[2], ss[0], unit.gg, unit.gb, k[0], k[1], k[2], C, 0)
+        ext.rows_op(4, M, d2d, buf2d, k[1], k[2], d2d, H, W, False)
+        unit.stage._unit_grads_ready(unit)
+        return dbuf, None, None, None
+
+
+class HeadUnit:
+    def __init__(self, stage: "NativeDenseNetStage") -> None:
+        self.stage, self.name = stage, "head"
+        self.param_names: List[str] = []
+
+    def bind(self) -> None:
+        st = self.stage
+        self.g, self.gg = st.pv("features.norm5.weight")
+        self.b, self.gb = st.pv("features.norm5.bias")
+        self.rm, self.rv = st.bv("features.norm5.running_mean"), st.bv("features.norm5.running_var")
+        self.param_names = ["features.norm5.weight", "features.norm5.bias"]
+
+    def __call__(self, x, in_stats):
+        pooled = _HeadPoolFn.apply(x, self.stage.anchor, self, in_stats)
+        cls = self.stage.classifier
+        return F.linear(pooled, cls.weight, cls.bias), None      # autograd + rocBLAS; grads land in the arena views
+
+
+class StemUnit:
+    """conv0 7x7/2 + norm0 + ReLU + maxpool 3x3/2 through PyTorch-ROCm (MIOpen) - scaffolding for the
+    4% of the FLOPs that are not yet native; output re-laid-out to NHWC for the first dense block."""
+
+    def __init__(self, stage: "NativeDenseNetStage") -> None:
+        self.stage, self.name = stage, "stem"
+        self.param_names: List[str] = []
+
+    def bind(self) -> None:
+        pass
+
+    def __call__(self, x, in_stats):
+        f = self.stage.features
+        x = ops.normalize_input(x, channels_last=False) if x.dtype == torch.uint8 else x
+        y = f.pool0(F.relu(f.norm0(f.conv0(x)), inplace=True))
+        return y.permute(0, 2, 3, 1).contiguous(), None
+
+
+# ======================================================================================
+# the stage module
+# ======================================================================================
+class NativeDenseNetStage(nn.Module):
+    """Drop-in for ``DenseNetStage`` on a GPU.  Input: uint8/float NCHW images (first stage) or an
+    NHWC activation (later stages); output: NHWC activation, or logits on the last stage."""
+
+    def __init__(self, units: Sequence[str] = UNIT_NAMES, num_classes: int = 5, device="cuda",
+                 dtype: str = "fp32", bucket_mb: float = 8.0, dp_world: int = 1,
+                 wgrad_min_rows: int = 256) -> None:
+        super().__init__()
+        if dtype != "fp32":
+            raise NotImplementedError("the native engine is fp32 (reference parity); bf16 MFMA mode is not built yet")
+        ops.require_ext()
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise ValueError("NativeDenseNetStage needs a GPU")
+        self.units = tuple(units)
+        self.num_classes = num_classes
+        self.wgrad_min_rows = wgrad_min_rows
+        ref = DenseNetStage(self.units, num_classes)          # same init distribution as the reference
+        self.features = ref.features
+        if "head" in self.units:
+            self.classifier = ref.classifier
+        # re-lay-out conv weights for the MFMA kernels
+        for name, mod in self.named_modules():
+            if isinstance(mod, nn.Conv2d) and name != "features.conv0":
+                mod.weight = nn.Parameter(self._to_native(mod.weight.data))
+        self.to(device)
+        self.arena = FlatArena(reverse_named_parameters(self), device=device,
+                               segment_numel=max(int(bucket_mb * 2 ** 20 / 4), 1),
+                               segment_multiple=max(dp_world, 1) * 64)
+        self.flat_buffers = FlatBuffers(self, device)
+        self.param_index: Dict[str, int] = {n: i for i, n in enumerate(self.arena.names)}
+        self._buffers_by_name = dict(self.named_buffers())
+        self.anchor = torch.zeros(1, device=device, requires_grad=True)   # keeps every unit in the graph
+        self.ones = torch.ones(1024, device=device)
+        self._grad_ready_cb = None
+        self.unit_objs = []
+        for u in self.units:
+            if u == "stem":
+                self.unit_objs.append(StemUnit(self))
+            elif u.startswith("denseblock"):
+                self.unit_objs.append(BlockUnit(self, u))
+            elif u.startswith("transition"):
+                self.unit_objs.append(TransitionUnit(self, u))
+            else:
+                self.unit_objs.append(HeadUnit(self))
+        for u in self.unit_objs:
+            u.bind()
+
+    # ---- layout conversion (checkpoint boundary) -------------------------------------------
+    @staticmethod
+    def _to_native(w: torch.Tensor) -> torch.Tensor:
+        n, c, kh, kw = w.shape
+        return w.permute(0, 2, 3, 1).reshape(n, kh * kw * c).contiguous()
+
+    def _is_native_conv(self, fqn: str) -> bool:
+        return fqn.endswith(("conv1.weight", "conv2.weight", "conv.weight")) and "conv0" not in fqn
+
+    def ddl_export_tensor(self, fqn: str, t: torch.Tensor) -> torch.Tensor:
+        if not self._is_native_conv(fqn) or t.dim() != 2:
+            return t
+        k = 3 if fqn.endswith("conv2.weight") else 1
+        n, kc = t.shape
+        return t.reshape(n, k, k, kc // (k * k)).permute(0, 3, 1, 2).contiguous()
+
+    def ddl_import_tensor(self, fqn: str, t: torch.Tensor) -> torch.Tensor:
+        if not self._is_native_conv(fqn) or t.dim() != 4:
+            return t
+        return self._to_native(t)
+
+    def export_state_dict(self) -> Dict[str, torch.Tensor]:
+        """State-dict in the torchvision layout (loadable by ``DenseNetStage``)."""
+        out = {}
+        for k, v in self.state_dict().items():
+            out[k] = self.ddl_export_tensor(k, v.detach()).clone()
+        return out
+
+    @torch.no_grad()
+    def import_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        for k, p in self.named_parameters():
+            p.data.copy_(self.ddl_import_tensor(k, sd[k]))
+        for k, b in self.named_buffers():
+            b.data.copy_(sd[k])
+
+    # ---- views ---------------------------------------------------------------------------
+    def pv(self, fqn: str) -> Tuple[torch.Tensor, torch.Tensor]:
+        i = self.param_index[fqn]
+        return self.arena.param_view(i), self.arena.grad_view(i)
+
+    def bv(self, fqn: str) -> torch.Tensor:
+        return self._buffers_by_name[fqn]
+
+    # ---- DP integration ------------------------------------------------------------------
+    def set_grad_ready_callback(self, cb) -> None:
+        """``cb(slot_index)`` is called when a natively computed parameter gradient is final."""
+        self._grad_ready_cb = cb
+
+    def _unit_grads_ready(self, unit) -> None:
+        if self._grad_ready_cb is not None:
+            for n in unit.param_names:
+                self._grad_ready_cb(self.param_index[n])
+
+    # ---- forward -------------------------------------------------------------------------
+    @property
+    def is_first(self) -> bool:
+        return self.units[0] == "stem"
+
+    @property
+    def is_last(self) -> bool:
+        return self.units[-1] == "head"
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        stats = None
+        for u in self.unit_objs:
+            x, stats = u(x, stats)
+        if self.training:
+            # num_batches_tracked of the natively handled BN layers (+1 per forward, one launch);
+            # norm0 goes through F.batch_norm, which bumps its own counter
+            self._bump_counters()
+        return x
+
+    def _bump_counters(self) -> None:
+        fi = self.flat_buffers.flat_int
+        if fi.numel() == 0:
+            return
+        fi.add_(1)
+        if self.is_first:
+            self.features.norm0.num_batches_tracked.sub_(1)
+
+    def output_shape(self, in_shape):
+        """NHWC output shape for an NCHW (first stage) / NHWC input shape."""
+        if self.is_first:
+            s = tuple(in_shape)
+        else:
+            s = (in_shape[0], in_shape[3], in_shape[1], in_shape[2])
+        for u in self.units:
+            s = DenseNetStage.unit_output_shape(u, s)
+        if self.is_last:
+            return (s[0], self.num_classes)
+        return (s[0], s[2], s[3], s[1])

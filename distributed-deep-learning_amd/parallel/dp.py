@@ -86,6 +86,8 @@ class DataParallelEngine:
             for i, p in enumerate(self.arena.params):
                 if p.requires_grad:
                     p.register_post_accumulate_grad_hook(self._make_hook(i))
+            if hasattr(module, "set_grad_ready_callback"):
+                module.set_grad_ready_callback(self.param_ready)
 
     # ------------------------------------------------------------------ state sync
     def broadcast_state(self) -> None:
@@ -118,15 +120,19 @@ class DataParallelEngine:
             self._pending[k] = sum(1 for i in seg.slots if self.arena.params[i].requires_grad)
             self._launched[k] = False
 
-    def _make_hook(self, slot_index: int) -> Callable:
+    def param_ready(self, slot_index: int) -> None:
+        """The gradient of arena slot ``slot_index`` is final (autograd hook, or the native
+        engine's per-unit callback for gradients it writes into the arena itself)."""
+        if not self._armed:
+            return
         k = self._slot_segment[slot_index]
+        self._pending[k] -= 1
+        if self._pending[k] == 0:
+            self.segment_ready(k)
 
+    def _make_hook(self, slot_index: int) -> Callable:
         def hook(param):
-            if not self._armed:
-                return
-            self._pending[k] -= 1
-            if self._pending[k] == 0:
-                self.segment_ready(k)
+            self.param_ready(slot_index)
         return hook
 
     @contextmanager

@@ -1,0 +1,217 @@
+"""Native gfx950 engine vs the plain-PyTorch fp32 DenseNet (same weights): kernels one by one, then
+whole units forward + backward, then a full training step."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from ddl import ops
+    ops.require_ext()
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    return torch.device("cuda", 0)
+
+
+def _rand(*shape, dev, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+
+@pytest.mark.parametrize("M,C,N,Cf,bm", [(300, 64, 128, 256, 0), (3136, 96, 128, 256, 128), (1000, 224, 128, 256, 64),
+                                          (130, 512, 256, 512, 32), (94, 992, 128, 1024, 0)])
+def test_conv1x1_fwd_prefix_prologue_stats(dev, M, C, N, Cf, bm):
+    """out = relu(x[:, :C]*sc+sh) @ W^T reading a channel prefix of a wider buffer, + column stats.
+    Asymmetric operands (random) would expose a swapped MFMA C/D map."""
+    from ddl import ops
+    ext = ops.require_ext()
+    buf = _rand(M, Cf, dev=dev, seed=1)
+    sc, sh = _rand(Cf, dev=dev, seed=2).abs() + 0.5, _rand(Cf, dev=dev, seed=3)
+    w = _rand(N, C, dev=dev, seed=4, scale=0.1)
+    out = torch.full((M, N), float("nan"), device=dev)
+    st = ext.conv_gemm(buf[:, :C], None, sc, None, sh, True, M, 1, 1, 1, False, w, False, out, False, False,
+                       None, None, None, 1, bm)
+    ref = torch.relu(buf[:, :C].double() * sc[:C].double() + sh[:C].double()) @ w.double().t()
+    torch.testing.assert_close(out.double(), ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(st[:, 0].sum(0).double(), ref.sum(0), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(st[:, 1].sum(0).double(), (ref * ref).sum(0), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("B,H,W,bm", [(2, 14, 14, 0), (3, 7, 7, 32), (1, 56, 56, 128), (5, 28, 28, 64)])
+def test_conv3x3_fwd_slice_write(dev, B, H, W, bm):
+    from ddl import ops
+    from ddl.models.native_densenet import NativeDenseNetStage
+    ext = ops.require_ext()
+    M, C, N, Cf = B * H * W, 128, 32, 256
+    h = _rand(M, C, dev=dev, seed=1)
+    sc, sh = _rand(C, dev=dev, seed=2).abs() + 0.5, _rand(C, dev=dev, seed=3)
+    w = _rand(N, C, 3, 3, dev=dev, seed=4, scale=0.05)
+    buf = torch.zeros(M, Cf, device=dev)
+    st = ext.conv_gemm(h, None, sc, None, sh, True, M, H, W, 9, False, NativeDenseNetStage._to_native(w), False,
+                       buf[:, 96:128], False, False, None, None, None, 1, bm)
+    a = torch.relu(h * sc + sh).view(B, H, W, C).permute(0, 3, 1, 2)
+    ref = F.conv2d(a.double(), w.double(), padding=1).permute(0, 2, 3, 1).reshape(M, N)
+    torch.testing.assert_close(buf[:, 96:128].double(), ref, rtol=1e-4, atol=1e-4)
+    assert buf[:, :96].abs().sum() == 0 and buf[:, 128:].abs().sum() == 0      # only the slice was written
+    torch.testing.assert_close(st[:, 0].sum(0).double(), ref.sum(0), rtol=1e-4, atol=1e-2)
+
+
+def _ref_stage(units, dev, seed=0):
+    from ddl.models.densenet import DenseNetStage
+    torch.manual_seed(seed)
+    ref = DenseNetStage(units, 5).to(dev)
+    with torch.no_grad():
+        for m in ref.modules():                      # non-trivial BN affine + running stats
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    return ref
+
+
+def _native_from(ref, units, dev):
+    from ddl.models.native_densenet import NativeDenseNetStage
+    nat = NativeDenseNetStage(units, 5, dev)
+    nat.import_state_dict(ref.state_dict())
+    return nat
+
+
+def _relerr(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def _compare_unit(dev, units, in_shape_nchw, tol=2e-5, slack=4.0, global_l2=False):
+    """Native engine vs the PyTorch model, both judged against an fp64 run of the PyTorch model.
+    Deep random-init BN stacks on tiny batches are ill-conditioned (ReLU masks flip on 1e-7
+    perturbations), so the criterion is: native error <= max(tol, slack * error of torch fp32)."""
+    ref = _ref_stage(units, dev)
+    nat = _native_from(ref, units, dev)
+    ref64 = _ref_stage(units, dev).double()
+    ref64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
+    x = _rand(*in_shape_nchw, dev=dev, seed=5)
+    first, last = units[0] == "stem", units[-1] == "head"
+    xr = x.clone().requires_grad_(not first)
+    x64 = x.double().requires_grad_(not first)
+    xn = (x if first else x.permute(0, 2, 3, 1).contiguous()).clone().requires_grad_(not first)
+    for m in (ref, nat, ref64):
+        m.train()
+    yr, yn, y64 = ref(xr), nat(xn), ref64(x64)
+    yn_cmp = yn if last else yn.permute(0, 3, 1, 2)
+    assert _relerr(yn_cmp, y64) <= max(tol, slack * _relerr(yr, y64)), "forward"
+    gy = _rand(*yr.shape, dev=dev, seed=6)
+    yr.backward(gy)
+    y64.backward(gy.double())
+    nat.arena.zero_grad()
+    yn.backward(gy if last else gy.permute(0, 2, 3, 1).contiguous())
+    if not first:
+        e_nat, e_ref = _relerr(xn.grad.permute(0, 3, 1, 2), x64.grad), _relerr(xr.grad, x64.grad)
+        assert e_nat <= max(tol, slack * e_ref), f"input grad: native {e_nat:.2e} torch {e_ref:.2e}"
+    g32, g64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    if global_l2:
+        # one flipped ReLU mask moves a single small-M weight gradient by percents; judge the whole
+        # gradient vector in L2 instead of each tensor in max-norm
+        gn = torch.cat([nat.ddl_export_tensor(n, p.grad).double().flatten() for n, p in nat.named_parameters()])
+        gr = torch.cat([g32[n].grad.double().flatten() for n, _ in nat.named_parameters()])
+        gd = torch.cat([g64[n].grad.flatten() for n, _ in nat.named_parameters()])
+        e_nat, e_ref = float((gn - gd).norm() / gd.norm()), float((gr - gd).norm() / gd.norm())
+        assert e_nat <= max(tol, slack * e_ref), f"global grad L2: native {e_nat:.2e} torch {e_ref:.2e}"
+    else:
+        for name, p in nat.named_parameters():
+            g = nat.ddl_export_tensor(name, p.grad)
+            e_nat, e_ref = _relerr(g, g64[name].grad), _relerr(g32[name].grad, g64[name].grad)
+            assert e_nat <= max(10 * tol, slack * e_ref), f"{name}: native {e_nat:.2e} torch {e_ref:.2e}"
+    # running statistics updated identically
+    for (n1, b1), (n2, b2) in zip(ref.named_buffers(), nat.named_buffers()):
+        assert n1 == n2
+        torch.testing.assert_close(b2.float(), b1.float(), rtol=1e-3, atol=1e-4, msg=lambda m: f"{n1}: {m}")
+    # eval mode (running statistics)
+    for m in (ref, nat, ref64):
+        m.eval()
+    ref64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
+    with torch.no_grad():
+        yr, yn, y64 = ref(xr), nat(xn), ref64(x64)
+    assert _relerr(yn if last else yn.permute(0, 3, 1, 2), y64) <= max(tol, slack * _relerr(yr, y64)), "eval forward"
+
+
+def test_dense_block_fwd_bwd(dev):
+    _compare_unit(dev, ("denseblock1",), (2, 64, 16, 16))
+
+
+def test_dense_block4_small_spatial(dev):
+    _compare_unit(dev, ("denseblock4",), (3, 512, 7, 7))
+
+
+def test_transition_fwd_bwd(dev):
+    _compare_unit(dev, ("transition2",), (2, 512, 8, 8))
+
+
+def test_block_transition_block(dev):
+    # chained units on a tiny batch are chaotic: a ReLU pre-activation within 1e-7 of zero flips
+    # between implementations (torch fp32 itself lands 6e-3 away from fp64 on some runs), so this
+    # test only checks agreement at that level; the single-unit tests pin exactness (~1e-6)
+    _compare_unit(dev, ("denseblock2", "transition2", "denseblock3"), (2, 128, 8, 8), tol=3e-2, global_l2=True)
+
+
+def test_head_fwd_bwd(dev):
+    _compare_unit(dev, ("denseblock4", "head"), (4, 512, 7, 7))
+
+
+def test_full_model_fwd_bwd(dev):
+    from ddl.models.densenet import UNIT_NAMES
+    # 121 BN layers deep on a 2-image batch: chaotic (torch fp32 itself is ~1e-3..1e-2 from fp64 here),
+    # so only agreement at that level is meaningful; the unit tests above pin exactness
+    _compare_unit(dev, UNIT_NAMES, (4, 3, 64, 64), tol=3e-2, slack=20.0, global_l2=True)
+
+
+def test_checkpoint_layout_roundtrip(dev, tmp_path):
+    """A native-engine checkpoint has the torchvision tensor layout and loads into the PyTorch model."""
+    from ddl import checkpoint as ck
+    from ddl.models.densenet import DenseNetStage
+    from ddl.optim import FusedAdam
+    units = ("denseblock4", "head")
+    nat = _native_from(_ref_stage(units, dev), units, dev)
+    opt = FusedAdam(nat.arena)
+    nat.train()
+    nat(_rand(2, 7, 7, 512, dev=dev)).sum().backward()
+    opt.step()
+    path = str(tmp_path / "snap")
+    ck.save_snapshot(path, 3, nat, opt)
+    ref = DenseNetStage(units, 5).to(dev)
+    ropt = torch.optim.Adam(ref.parameters())
+    assert ck.load_snapshot(path, ref, ropt) == 3
+    sd = nat.export_state_dict()
+    for k, v in ref.state_dict().items():
+        torch.testing.assert_close(v, sd[k])
+    k = "features.denseblock4.denselayer3.conv2.weight"
+    p = dict(ref.named_parameters())[k]
+    assert tuple(ropt.state[p]["exp_avg"].shape) == (32, 128, 3, 3)
+
+
+def test_training_step_matches_reference_trajectory(dev):
+    """3 Adam steps of the native engine track the PyTorch model started from the same weights."""
+    from ddl import comm
+    from ddl.config import TrainConfig
+    from ddl.models.densenet import UNIT_NAMES
+    from ddl.trainer import SingleStrategy
+    cfg = TrainConfig(strategy="single", batch_size=4, impl="native")
+    strat = SingleStrategy(cfg, comm.CommContext(0, 1, 0, dev, "none"))
+    ref = _ref_stage(UNIT_NAMES, dev)
+    strat.model.import_state_dict(ref.state_dict())
+    ropt = torch.optim.Adam(ref.parameters())
+    g = torch.Generator().manual_seed(0)
+    x = torch.randint(0, 256, (4, 3, 64, 64), dtype=torch.uint8, generator=g).to(dev)
+    y = torch.randint(0, 5, (4,), generator=g).to(dev)
+    ref.train()
+    for _ in range(3):
+        loss, out, preds = strat.train_step(x, y, 4)
+        ropt.zero_grad()
+        rl = F.cross_entropy(ref(x), y)
+        rl.backward()
+        ropt.step()
+        assert abs(float(loss) - float(rl)) < 5e-3 * max(1.0, abs(float(rl)))
