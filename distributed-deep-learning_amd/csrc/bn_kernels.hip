@@ -10,7 +10,7 @@
 //    (scale = gamma*rstd, shift = beta - mean*scale) from the shared table.  The 58 full-tensor
 //    statistics passes of the reference disappear.
 //  * `bn_prep` / `bn_bwd_prep` are one workgroup per 32 channels (channels are independent):
-//    8 slices x 32 channels reduce the per-tile partials in double precision, then the per-channel
+//    32 slices x 32 channels reduce the per-tile partials (fp32 lanes, double combine), then the per-channel
 //    scalars are produced.  Nothing here touches pixel data.
 //  * `rows_op` is the single skeleton for the pixel-touching glue ops: a workgroup owns a tile of
 //    rows, each thread a fixed float4 channel column, so per-channel sums stay in registers and
@@ -25,21 +25,36 @@ namespace {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
-// sum partials[g][which][c] over g for 32 channels with 8 slices of the workgroup (256 threads)
+// sum partials[g][which][c] over g for 32 channels with the 32 slices of a 1024-thread workgroup;
+// loads are issued 4 deep (independent accumulators) so the table read is not one long dependent chain
+constexpr int PREP_SLICES = 32;
 __device__ __forceinline__ void reduce_partials32(const float* __restrict__ partials, int G, int ldp,
                                                   int c_local0, double* s_a, double* s_b,
                                                   double (*red)[2][32]) {
   const int ch = threadIdx.x & 31, slice = threadIdx.x >> 5;
-  double a = 0.0, b = 0.0;
-  for (int g = slice; g < G; g += 8) {
-    a += (double)partials[((long)g * 2 + 0) * ldp + c_local0 + ch];
-    b += (double)partials[((long)g * 2 + 1) * ldp + c_local0 + ch];
+  const float* base = partials + c_local0 + ch;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+  int g = slice;
+  for (; g + 3 * PREP_SLICES < G; g += 4 * PREP_SLICES) {
+    a0 += base[((long)g * 2 + 0) * ldp];
+    b0 += base[((long)g * 2 + 1) * ldp];
+    a1 += base[((long)(g + PREP_SLICES) * 2 + 0) * ldp];
+    b1 += base[((long)(g + PREP_SLICES) * 2 + 1) * ldp];
+    a2 += base[((long)(g + 2 * PREP_SLICES) * 2 + 0) * ldp];
+    b2 += base[((long)(g + 2 * PREP_SLICES) * 2 + 1) * ldp];
+    a3 += base[((long)(g + 3 * PREP_SLICES) * 2 + 0) * ldp];
+    b3 += base[((long)(g + 3 * PREP_SLICES) * 2 + 1) * ldp];
   }
-  red[slice][0][ch] = a;
-  red[slice][1][ch] = b;
+  for (; g < G; g += PREP_SLICES) {
+    a0 += base[((long)g * 2 + 0) * ldp];
+    b0 += base[((long)g * 2 + 1) * ldp];
+  }
+  red[slice][0][ch] = ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+  red[slice][1][ch] = ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
   __syncthreads();
   if (slice == 0) {
-    for (int s = 1; s < 8; ++s) { a += red[s][0][ch]; b += red[s][1][ch]; }
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < PREP_SLICES; ++s) { a += red[s][0][ch]; b += red[s][1][ch]; }
     s_a[ch] = a;
     s_b[ch] = b;
   }
@@ -55,13 +70,13 @@ __device__ __forceinline__ void reduce_partials32(const float* __restrict__ part
 //          momentum update (unbiased variance, like torch).
 //   eval : scale/shift from the running statistics.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) bn_prep_kernel(
+__global__ void __launch_bounds__(1024) bn_prep_kernel(
     const float* __restrict__ partials, int G, int ldp, int new0, int n_new, double count,
     float* __restrict__ chan_mean, float* __restrict__ chan_var, float* __restrict__ chan_rstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ run_mean,
     float* __restrict__ run_var, float* __restrict__ scale, float* __restrict__ shift, int C,
     float momentum, float eps, int train) {
-  __shared__ double red[8][2][32];
+  __shared__ double red[PREP_SLICES][2][32];
   __shared__ double s_a[32], s_b[32];
   const int c0 = blockIdx.x * 32;
   const int ch = threadIdx.x & 31;
@@ -103,7 +118,7 @@ void launch_bn_prep(const float* partials, int G, int ldp, int new0, int n_new, 
                     float* chan_mean, float* chan_var, float* chan_rstd, const float* gamma,
                     const float* beta, float* run_mean, float* run_var, float* scale, float* shift,
                     int C, float momentum, float eps, bool train, hipStream_t s) {
-  hipLaunchKernelGGL(bn_prep_kernel, dim3((C + 31) / 32), dim3(256), 0, s, partials, G, ldp, new0, n_new,
+  hipLaunchKernelGGL(bn_prep_kernel, dim3((C + 31) / 32), dim3(1024), 0, s, partials, G, ldp, new0, n_new,
                      count, chan_mean, chan_var, chan_rstd, gamma, beta, run_mean, run_var, scale, shift,
                      C, momentum, eps, train ? 1 : 0);
 }
@@ -116,12 +131,12 @@ void launch_bn_prep(const float* partials, int G, int ldp, int new0, int n_new, 
 //   mode 0: write (k0 = sc, k1, k2) - consumed by the next kernel's two-source prologue
 //   mode 1: accumulate the deferred dense-block terms  NQ += k1 , NP += k2  (dX = dBuf + NQ*x + NP)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) bn_bwd_prep_kernel(
+__global__ void __launch_bounds__(1024) bn_bwd_prep_kernel(
     const float* __restrict__ partials, int G, int ldp, double count, const float* __restrict__ chan_mean,
     const float* __restrict__ chan_rstd, const float* __restrict__ scale, float* __restrict__ dgamma,
     float* __restrict__ dbeta, float* __restrict__ k0, float* __restrict__ k1, float* __restrict__ k2,
     int C, int mode) {
-  __shared__ double red[8][2][32];
+  __shared__ double red[PREP_SLICES][2][32];
   __shared__ double s_a[32], s_b[32];
   const int c0 = blockIdx.x * 32;
   const int ch = threadIdx.x & 31;
@@ -150,7 +165,7 @@ __global__ void __launch_bounds__(256) bn_bwd_prep_kernel(
 void launch_bn_bwd_prep(const float* partials, int G, int ldp, double count, const float* chan_mean,
                         const float* chan_rstd, const float* scale, float* dgamma, float* dbeta, float* k0,
                         float* k1, float* k2, int C, int mode, hipStream_t s) {
-  hipLaunchKernelGGL(bn_bwd_prep_kernel, dim3((C + 31) / 32), dim3(256), 0, s, partials, G, ldp, count,
+  hipLaunchKernelGGL(bn_bwd_prep_kernel, dim3((C + 31) / 32), dim3(1024), 0, s, partials, G, ldp, count,
                      chan_mean, chan_rstd, scale, dgamma, dbeta, k0, k1, k2, C, mode);
 }
 

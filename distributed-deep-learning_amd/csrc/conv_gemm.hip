@@ -39,29 +39,45 @@ constexpr int LDK = BK + 4;
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-// one float4 of the row source at (row, c..c+3); zeros when !valid
-__device__ __forceinline__ f32x4 row_src_load(const RowSrc& a, long row, int c, bool valid) {
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+// Raw operand fetch and the deferred prologue.  The global loads of slab k+1 are issued before the
+// MFMAs of slab k and only *consumed* (affine + ReLU, then the LDS write) after them, so their
+// latency hides under the matrix work instead of stalling the wave at the load site.
+template <bool TWO>
+struct RawRow {
+  f32x4 v0, v1, s0, s1, s2;
+};
+
+template <bool TWO>
+__device__ __forceinline__ void row_src_fetch(RawRow<TWO>& r, const RowSrc& a, long row, int c, bool valid) {
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  r.v0 = z; r.v1 = z; r.s0 = z; r.s1 = z; r.s2 = z;
   if (valid) {
-    v = ld4(a.X0 + row * a.ld0 + c);
+    r.v0 = ld4(a.X0 + row * a.ld0 + c);
     if (a.s0 != nullptr) {
-      const f32x4 s0 = ld4(a.s0 + c);
-      const f32x4 s2 = ld4(a.s2 + c);
-      v = s0 * v + s2;
-      if (a.X1 != nullptr) {
-        const f32x4 w = ld4(a.X1 + row * a.ld1 + c);
-        const f32x4 s1 = ld4(a.s1 + c);
-        v += s1 * w;
+      r.s0 = ld4(a.s0 + c);
+      r.s2 = ld4(a.s2 + c);
+      if (TWO) {
+        r.v1 = ld4(a.X1 + row * a.ld1 + c);
+        r.s1 = ld4(a.s1 + c);
       }
-      if (a.relu) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-      }
+    }
+  }
+}
+
+template <bool TWO>
+__device__ __forceinline__ f32x4 row_src_apply(const RawRow<TWO>& r, const RowSrc& a) {
+  f32x4 v = r.v0;
+  if (a.s0 != nullptr) {        // invalid rows carry s0 = s2 = 0 -> 0
+    v = r.s0 * v + r.s2;
+    if (TWO) v += r.s1 * r.v1;
+    if (a.relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
   }
   return v;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool TWO>
 __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const ConvGemmParams p) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / (32 * WM);
@@ -103,7 +119,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const ConvGemmP
     }
   }
 
-  f32x4 a_reg[PA], b_reg[PB];
+  RawRow<TWO> a_raw[PA];
+  f32x4 b_reg[PB];
 
   auto load_slab = [&](int kt) {
     const int tap = kt / cchunks;
@@ -124,7 +141,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const ConvGemmP
         const int yy = a_y[i] + dy, xx = a_x[i] + dx;
         ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
       }
-      a_reg[i] = row_src_load(p.a, a_m[i] + off, c, ok);
+      row_src_fetch<TWO>(a_raw[i], p.a, a_m[i] + off, c, ok);
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
@@ -150,7 +167,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const ConvGemmP
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       const int f = tid + i * NT;
-      *reinterpret_cast<f32x4*>(Ab + (f >> 3) * LDK + 4 * (f & 7)) = a_reg[i];
+      *reinterpret_cast<f32x4*>(Ab + (f >> 3) * LDK + 4 * (f & 7)) = row_src_apply<TWO>(a_raw[i], p.a);
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
@@ -264,17 +281,23 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const ConvGemmP
   }
 }
 
-template <int BM, int BN, int WM, int WN>
-void launch_cfg(const ConvGemmParams& p, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, bool TWO>
+void launch_cfg2(const ConvGemmParams& p, hipStream_t s) {
   constexpr size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, TWO>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.N + BN - 1) / BN));
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), grid, dim3(64 * WM * WN), lds, s, p);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, TWO>), grid, dim3(64 * WM * WN), lds, s, p);
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch_cfg(const ConvGemmParams& p, hipStream_t s) {
+  if (p.a.X1 != nullptr) launch_cfg2<BM, BN, WM, WN, true>(p, s);
+  else launch_cfg2<BM, BN, WM, WN, false>(p, s);
 }
 
 }  // namespace

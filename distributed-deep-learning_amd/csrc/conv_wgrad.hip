@@ -28,23 +28,54 @@ namespace {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-__device__ __forceinline__ f32x4 row_src_load(const RowSrc& a, long row, int c, bool valid) {
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+// Per-thread operand column state: a thread always stages the same channel quad, so the affine
+// vectors are fetched once; pixel data is fetched raw one step ahead and transformed only when it
+// is written to LDS (after the current step's MFMAs) - the loads' latency hides under the MFMAs.
+struct ColAffine {
+  f32x4 s0, s1, s2;
+  bool affine, two, relu;
+};
+
+__device__ __forceinline__ ColAffine col_affine(const RowSrc& a, int c, bool col_ok) {
+  ColAffine k;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  k.s0 = z; k.s1 = z; k.s2 = z;
+  k.affine = a.s0 != nullptr;
+  k.two = a.X1 != nullptr;
+  k.relu = a.relu != 0;
+  if (k.affine && col_ok) {
+    k.s0 = ld4(a.s0 + c);
+    k.s2 = ld4(a.s2 + c);
+    if (k.two) k.s1 = ld4(a.s1 + c);
+  }
+  return k;
+}
+
+struct RawPix {
+  f32x4 v0, v1;
+  bool ok;
+};
+
+__device__ __forceinline__ RawPix pix_fetch(const RowSrc& a, long row, int c, bool valid) {
+  RawPix r;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  r.v0 = z; r.v1 = z; r.ok = valid;
   if (valid) {
-    v = ld4(a.X0 + row * a.ld0 + c);
-    if (a.s0 != nullptr) {
-      const f32x4 s0 = ld4(a.s0 + c);
-      const f32x4 s2 = ld4(a.s2 + c);
-      v = s0 * v + s2;
-      if (a.X1 != nullptr) {
-        const f32x4 w = ld4(a.X1 + row * a.ld1 + c);
-        const f32x4 s1 = ld4(a.s1 + c);
-        v += s1 * w;
-      }
-      if (a.relu) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-      }
+    r.v0 = ld4(a.X0 + row * a.ld0 + c);
+    if (a.X1 != nullptr) r.v1 = ld4(a.X1 + row * a.ld1 + c);
+  }
+  return r;
+}
+
+__device__ __forceinline__ f32x4 pix_apply(const RawPix& r, const ColAffine& k) {
+  f32x4 v = r.v0;
+  if (k.affine) {
+    v = k.s0 * v + k.s2;
+    if (k.two) v += k.s1 * r.v1;
+    if (k.relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
+    if (!r.ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   return v;
 }
@@ -68,24 +99,26 @@ __global__ void __launch_bounds__(256) wgrad1x1_kernel(const WgradParams p) {
   if (me > p.M) me = p.M;
   const int steps = (int)((me - mb + RK - 1) / RK);
 
-  f32x4 d_reg[4], a_reg[4];
+  const int q = 4 * (tid & 31);          // this thread's channel quad in both tiles (f & 31 == tid & 31)
+  const ColAffine kd = col_affine(p.d, n0 + q, n0 + q < p.N);
+  const ColAffine ka = col_affine(p.a, c0 + q, c0 + q < p.C);
+  RawPix d_raw[4], a_raw[4];
   auto load_step = [&](int st) {
     const long mrow = mb + (long)st * RK;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int f = tid + i * 256;
       const long m = mrow + (f >> 5);
-      const int q = 4 * (f & 31);
-      d_reg[i] = row_src_load(p.d, m, n0 + q, m < me && n0 + q < p.N);
-      a_reg[i] = row_src_load(p.a, m, c0 + q, m < me && c0 + q < p.C);
+      d_raw[i] = pix_fetch(p.d, m, n0 + q, m < me && n0 + q < p.N);
+      a_raw[i] = pix_fetch(p.a, m, c0 + q, m < me && c0 + q < p.C);
     }
   };
   auto store_step = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int f = tid + i * 256;
-      *reinterpret_cast<f32x4*>(Ds + buf * RK * 128 + (f >> 5) * 128 + 4 * (f & 31)) = d_reg[i];
-      *reinterpret_cast<f32x4*>(As + buf * RK * 128 + (f >> 5) * 128 + 4 * (f & 31)) = a_reg[i];
+      *reinterpret_cast<f32x4*>(Ds + buf * RK * 128 + (f >> 5) * 128 + q) = pix_apply(d_raw[i], kd);
+      *reinterpret_cast<f32x4*>(As + buf * RK * 128 + (f >> 5) * 128 + q) = pix_apply(a_raw[i], ka);
     }
   };
 
@@ -155,20 +188,23 @@ __global__ void __launch_bounds__(256) wgrad3x3_kernel(const WgradParams p) {
   if (me > p.M) me = p.M;
   const int steps = (int)((me - mb + RK - 1) / RK);
 
-  f32x4 d_reg, a_reg[5];
+  const ColAffine kd = col_affine(p.d, 4 * (tid & 7), true);
+  const ColAffine ka = col_affine(p.a, cbase + 4 * (tid & 31), cbase + 4 * (tid & 31) < p.C);
+  RawPix d_raw, a_raw[5];
   int fl_reg = 0;
   auto load_step = [&](int st) {
     const long mrow = mb + (long)st * RK;
     {   // dO tile: 32 rows x 32 channels = 256 float4
       const long m = mrow + (tid >> 3);
-      d_reg = row_src_load(p.d, m, 4 * (tid & 7), m < me);
+      d_raw = pix_fetch(p.d, m, 4 * (tid & 7), m < me);
     }
 #pragma unroll
     for (int i = 0; i < 5; ++i) {   // activation rows mrow-1+dy*W ... (+AR), 128 channels
       const int f = tid + i * 256;
       const int r = f >> 5;
       const long ms = mrow - 1 + (long)dy * p.W + r;
-      a_reg[i] = row_src_load(p.a, ms, cbase + 4 * (f & 31), r < AR && ms >= 0 && ms < p.M);
+      a_raw[i] = pix_fetch(p.a, ms, cbase + 4 * (f & 31),
+                           r < AR && ms >= 0 && ms < p.M && cbase + 4 * (f & 31) < p.C);
     }
     if (tid < RK) {
       const long m = mrow + tid;
@@ -186,12 +222,12 @@ __global__ void __launch_bounds__(256) wgrad3x3_kernel(const WgradParams p) {
     }
   };
   auto store_step = [&](int buf) {
-    *reinterpret_cast<f32x4*>(Ds + buf * RK * 32 + (tid >> 3) * 32 + 4 * (tid & 7)) = d_reg;
+    *reinterpret_cast<f32x4*>(Ds + buf * RK * 32 + (tid >> 3) * 32 + 4 * (tid & 7)) = pix_apply(d_raw, kd);
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const int f = tid + i * 256;
       if ((f >> 5) < AR)
-        *reinterpret_cast<f32x4*>(As + buf * AR * 128 + (f >> 5) * 128 + 4 * (f & 31)) = a_reg[i];
+        *reinterpret_cast<f32x4*>(As + buf * AR * 128 + (f >> 5) * 128 + 4 * (f & 31)) = pix_apply(a_raw[i], ka);
     }
     if (tid < RK) Fl[buf * RK + tid] = fl_reg;
   };
@@ -242,15 +278,33 @@ __global__ void __launch_bounds__(256) wgrad3x3_kernel(const WgradParams p) {
   }
 }
 
-// dW[e] += sum_s slabs[s][e]   (fixed order => deterministic)
+// dW[e] += sum_s slabs[s][e]: 16 float4 columns x 16 S-slices per workgroup, independent loads
+// 4 deep, fixed combine order => deterministic.
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, int S,
                                                           long total4, float* __restrict__ dW) {
-  const long i = blockIdx.x * 256L + threadIdx.x;
-  if (i >= total4) return;
+  __shared__ f32x4 red[16][16];
+  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long i = blockIdx.x * 16L + col;
   const f32x4* src = reinterpret_cast<const f32x4*>(slabs);
-  f32x4 s = reinterpret_cast<f32x4*>(dW)[i];
-  for (int k = 0; k < S; ++k) s += src[(long)k * total4 + i];
-  reinterpret_cast<f32x4*>(dW)[i] = s;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  if (i < total4) {
+    int k = sl;
+    for (; k + 48 < S; k += 64) {
+      a0 += src[(long)k * total4 + i];
+      a1 += src[(long)(k + 16) * total4 + i];
+      a2 += src[(long)(k + 32) * total4 + i];
+      a3 += src[(long)(k + 48) * total4 + i];
+    }
+    for (; k < S; k += 16) a0 += src[(long)k * total4 + i];
+  }
+  red[sl][col] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (sl == 0 && i < total4) {
+    f32x4 s = reinterpret_cast<f32x4*>(dW)[i];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][col];
+    reinterpret_cast<f32x4*>(dW)[i] = s;
+  }
 }
 
 }  // namespace
@@ -258,7 +312,7 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
 // rows per workgroup (multiple of 32) for a weight-gradient launch: as many chunks as it takes
 // to fill the chip, but never so many that the slab traffic outweighs the operand traffic.
 int wgrad_rows_per_wg(int M, int other_grid, int min_rows) {
-  long want_chunks = (1024 + other_grid - 1) / other_grid;
+  long want_chunks = (768 + other_grid - 1) / other_grid;
   long rows = (M + want_chunks - 1) / want_chunks;
   if (rows < min_rows) rows = min_rows;
   rows = (rows + 31) / 32 * 32;
@@ -284,7 +338,7 @@ void launch_wgrad(const WgradParams& p, float* dW, hipStream_t s) {
     hipLaunchKernelGGL(wgrad3x3_kernel, grid, dim3(256), lds3, s, p);
   }
   const long total4 = (long)p.N * p.taps * p.C / 4;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s,
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total4 + 15) / 16)), dim3(256), 0, s,
                      p.slabs, p.S, total4, dW);
 }
 

@@ -348,7 +348,7 @@ class NativeDenseNetStage(nn.Module):
 
     def __init__(self, units: Sequence[str] = UNIT_NAMES, num_classes: int = 5, device="cuda",
                  dtype: str = "fp32", bucket_mb: float = 8.0, dp_world: int = 1,
-                 wgrad_min_rows: int = 256) -> None:
+                 wgrad_min_rows: int = 64) -> None:
         super().__init__()
         if dtype != "fp32":
             raise NotImplementedError("the native engine is fp32 (reference parity); bf16 MFMA mode is not built yet")
