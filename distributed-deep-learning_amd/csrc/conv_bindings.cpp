@@ -58,6 +58,7 @@ at::Tensor conv_gemm(const at::Tensor& x0, const OptT& x1, const OptT& s0, const
   const int64_t C = x0.size(1), N = out.size(1);
   TORCH_CHECK(taps == 1 || taps == 9, "taps must be 1 or 9");
   TORCH_CHECK(M > 0 && M < (1LL << 31), "bad M");
+  TORCH_CHECK(C % 32 == 0 && N % 4 == 0, "conv_gemm: C must be a multiple of 32 and N of 4");
   if (taps == 9) {
     TORCH_CHECK(H > 0 && W > 0 && M % (H * W) == 0, "M must be a whole number of HxW images");
   }

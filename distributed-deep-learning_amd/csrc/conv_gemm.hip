@@ -15,15 +15,21 @@
 //   * both data gradients, with ReLU/BN-backward masks, the per-channel BN-backward sums and the
 //     "+=" into the block's shared gradient buffer fused into the epilogue.
 //
-// Tiling (wave64): workgroup = WM x WN waves, each wave owns TM x TN MFMA tiles of 32x32
-// (16 accumulator VGPRs each).  K is walked in 32-wide slabs; A and B slabs are staged
-// global -> registers -> LDS ([rows][32+4] fp32, K contiguous, +4 pad => conflict-free
-// ds_read_b128 for the 16-lane groups) with the next slab's global loads in flight during the
-// current slab's MFMAs (register-staged double buffer, one barrier per slab).  A ds_read_b128
-// hands a lane 4 consecutive k; MFMA j of a group takes element j from both operands, so lane
-// half h contributes k = 8s + 4h + j - the same permutation on A and B, hence a valid reduction.
+// Tiling (wave64): a workgroup is WM x WN x KS waves.  Each wave owns TM x TN MFMA tiles of
+// 32x32 (16 accumulator VGPRs each); the KS wave groups split every K slab between them
+// (intra-workgroup split-K, combined through LDS at the end) - DenseNet at batch 30 has layers
+// with only 46..184 row tiles, and without the K split those run one wave per CU for 36 dependent
+// slabs.  K is walked in slabs of 32*KS (flat index over taps x channels); A and B slabs are
+// staged global -> registers -> LDS with the next slab's global loads issued BEFORE the current
+// slab's MFMAs and consumed (BN affine + ReLU, LDS write) AFTER them, one barrier per slab.
+// LDS images keep K contiguous with a +4 float pad ([rows][32*KS+4]): ds_read_b128 is
+// conflict-free for its 16-lane groups and hands a lane 4 consecutive k; MFMA e of a group takes
+// element e from both operands, so lane half h contributes k = 8s + 4h + e - the same
+// permutation on A and B, hence a valid reduction.  Weights that arrive K-major (the forward
+// tensor read transposed by the data-gradient) keep that orientation in LDS ([k][BN+4], b128
+// writes) and are read with four conflict-free ds_read_b32 instead of being transposed.
 // fp32 MFMA issues once per 64 cycles, so LDS and VALU (the fused prologue) are far from
-// limiting; what matters is keeping every SIMD's MFMA queue full and not re-reading HBM.
+// limiting; what matters is keeping every SIMD's MFMA queue fed.
 #include "conv_params.h"
 #include "ddl_kernels.h"
 
@@ -34,80 +40,59 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDK = BK + 4;
-
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-// Raw operand fetch and the deferred prologue.  The global loads of slab k+1 are issued before the
-// MFMAs of slab k and only *consumed* (affine + ReLU, then the LDS write) after them, so their
-// latency hides under the matrix work instead of stalling the wave at the load site.
-template <bool TWO>
-struct RawRow {
-  f32x4 v0, v1, s0, s1, s2;
-};
-
-template <bool TWO>
-__device__ __forceinline__ void row_src_fetch(RawRow<TWO>& r, const RowSrc& a, long row, int c, bool valid) {
-  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  r.v0 = z; r.v1 = z; r.s0 = z; r.s1 = z; r.s2 = z;
-  if (valid) {
-    r.v0 = ld4(a.X0 + row * a.ld0 + c);
-    if (a.s0 != nullptr) {
-      r.s0 = ld4(a.s0 + c);
-      r.s2 = ld4(a.s2 + c);
-      if (TWO) {
-        r.v1 = ld4(a.X1 + row * a.ld1 + c);
-        r.s1 = ld4(a.s1 + c);
-      }
-    }
-  }
-}
-
-template <bool TWO>
-__device__ __forceinline__ f32x4 row_src_apply(const RawRow<TWO>& r, const RowSrc& a) {
-  f32x4 v = r.v0;
-  if (a.s0 != nullptr) {        // invalid rows carry s0 = s2 = 0 -> 0
-    v = r.s0 * v + r.s2;
-    if (TWO) v += r.s1 * r.v1;
-    if (a.relu) {
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-    }
-  }
-  return v;
-}
-
-template <int BM, int BN, int WM, int WN, bool TWO>
-__global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const ConvGemmParams p) {
-  constexpr int NT = 64 * WM * WN;
+template <int BM, int BN, int WM, int WN, int KS, bool TWO, bool KMAJOR>
+__global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const ConvGemmParams p) {
+  constexpr int NT = 64 * WM * WN * KS;
   constexpr int TM = BM / (32 * WM);
   constexpr int TN = BN / (32 * WN);
-  constexpr int PA = (BM * 8) / NT;   // float4 loads per thread per A slab
-  constexpr int PB = (BN * 8) / NT;
-  static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "slab must divide over the workgroup");
+  constexpr int BKT = 32 * KS;           // K slab
+  constexpr int LDA = BKT + 4;           // LDS row stride of K-contiguous images
+  constexpr int LDBK = BN + 4;           // LDS row stride of the K-major weight image
+  constexpr int Q = 8 * KS;              // float4 per K-contiguous row
+  constexpr int RSTEP = NT / Q;          // rows covered per pass
+  constexpr int PA = (BM * Q) / NT;
+  constexpr int PB = (BN * Q) / NT;
+  constexpr int B_ELEMS = KMAJOR ? BKT * LDBK : BN * LDA;
+  static_assert((BM * Q) % NT == 0 && (BN * Q) % NT == 0 && NT % Q == 0, "slab must divide over the workgroup");
   static_assert(TM >= 1 && TN >= 1, "bad wave layout");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                    // [2][BM][LDK]
-  float* Bs = smem + 2 * BM * LDK;     // [2][BN][LDK]
+  float* As = smem;                        // [2][BM][LDA]
+  float* Bs = smem + 2 * BM * LDA;         // [2][B_ELEMS]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid / WN, wn = wid % WN;
+  const int ks = wid / (WM * WN);
+  const int wmn = wid - ks * (WM * WN);
+  const int wm = wmn / WN, wn = wmn - wm * WN;
   const int li = lane & 31, lh = lane >> 5;
-  const long m0 = (long)blockIdx.x * BM;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
+  // contiguous run of row tiles (neighbouring tiles share 3x3 halo rows in that XCD's L2)
+  int tile_x;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    tile_x = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const long m0 = (long)tile_x * BM;
   const int n0 = blockIdx.y * BN;
-  const int cchunks = (p.C + BK - 1) / BK;
-  const int KT = p.taps * cchunks;
+  const int cchunks = p.C >> 5;            // 32-wide sub-slabs per tap (C % 32 == 0, checked on host)
+  const int NS = p.taps * cchunks;         // sub-slabs in all
+  const int KT = (NS + KS - 1) / KS;
   const int HW = p.H * p.W;
 
-  // ---- per-thread row bookkeeping for the A slab ------------------------------------------
+  // ---- per-thread bookkeeping -----------------------------------------------------------------
+  const int aq = tid % Q;                  // this thread's float4 column inside a slab row
+  const int a_sub = aq >> 3;               // which 32-wide sub-slab
+  const int a_col = 4 * (aq & 7);          // channel offset inside it
+  const int a_row0 = tid / Q;
   long a_m[PA];
   int a_y[PA], a_x[PA];
   bool a_ok[PA];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
-    const int f = tid + i * NT;
-    const long m = m0 + (f >> 3);
+    const long m = m0 + a_row0 + i * RSTEP;
     a_m[i] = m;
     a_ok[i] = m < p.M;
     a_y[i] = 0;
@@ -119,68 +104,101 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const ConvGemmP
     }
   }
 
-  RawRow<TWO> a_raw[PA];
+  f32x4 a_v0[PA], a_v1[PA];
+  f32x4 a_s0, a_s1, a_s2;
+  unsigned a_mask = 0;
   f32x4 b_reg[PB];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   auto load_slab = [&](int kt) {
-    const int tap = kt / cchunks;
-    const int c0 = (kt - tap * cchunks) * BK;
-    int dy = 0, dx = 0;
-    if (p.taps > 1) {
-      dy = tap / 3 - 1;
-      dx = tap - (tap / 3) * 3 - 1;
-      if (p.flip) { dy = -dy; dx = -dx; }
-    }
-    const long off = (long)dy * p.W + dx;
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const int f = tid + i * NT;
-      const int c = c0 + 4 * (f & 7);
-      bool ok = a_ok[i] && c < p.C;
+    {   // ---- A: rows gathered with this thread's tap offset, raw values only ----
+      const int idx = kt * KS + a_sub;
+      const bool sub_ok = idx < NS;
+      const int tap = sub_ok ? idx / cchunks : 0;
+      const int c = (idx - tap * cchunks) * 32 + a_col;
+      int dy = 0, dx = 0;
       if (p.taps > 1) {
-        const int yy = a_y[i] + dy, xx = a_x[i] + dx;
-        ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+        dy = tap / 3 - 1;
+        dx = tap - (tap / 3) * 3 - 1;
+        if (p.flip) { dy = -dy; dx = -dx; }
       }
-      row_src_fetch<TWO>(a_raw[i], p.a, a_m[i] + off, c, ok);
+      const long off = (long)dy * p.W + dx;
+      a_s0 = zero4; a_s1 = zero4; a_s2 = zero4;
+      if (sub_ok && p.a.s0 != nullptr) {
+        a_s0 = ld4(p.a.s0 + c);
+        a_s2 = ld4(p.a.s2 + c);
+        if (TWO) a_s1 = ld4(p.a.s1 + c);
+      }
+      a_mask = 0;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        bool ok = a_ok[i] && sub_ok;
+        if (p.taps > 1) {
+          const int yy = a_y[i] + dy, xx = a_x[i] + dx;
+          ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+        }
+        a_v0[i] = zero4;
+        if (TWO) a_v1[i] = zero4;
+        if (ok) {
+          a_mask |= 1u << i;
+          a_v0[i] = ld4(p.a.X0 + (a_m[i] + off) * p.a.ld0 + c);
+          if (TWO) a_v1[i] = ld4(p.a.X1 + (a_m[i] + off) * p.a.ld1 + c);
+        }
+      }
     }
+    // ---- B ----
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       const int f = tid + i * NT;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (!p.b_kmajor) {
-        const int n = n0 + (f >> 3);
-        const int c = c0 + 4 * (f & 7);
-        if (n < p.N && c < p.C) v = ld4(p.Wt + (long)n * p.ldb + (long)tap * p.C + c);
+      f32x4 v = zero4;
+      if (!KMAJOR) {
+        const int n = n0 + f / Q;
+        const int bq = f % Q;
+        const int idx = kt * KS + (bq >> 3);
+        if (n < p.N && idx < NS) {
+          const int tap = idx / cchunks;
+          const int c = (idx - tap * cchunks) * 32 + 4 * (bq & 7);
+          v = ld4(p.Wt + (long)n * p.ldb + (long)tap * p.C + c);
+        }
       } else {
         const int kk = f / (BN / 4);
         const int n = n0 + 4 * (f - kk * (BN / 4));
-        const int c = c0 + kk;
-        if (n < p.N && c < p.C) v = ld4(p.Wt + (long)c * p.ldb + (long)tap * p.N + n);
+        const int idx = kt * KS + (kk >> 5);
+        if (n < p.N && idx < NS) {
+          const int tap = idx / cchunks;
+          const int c = (idx - tap * cchunks) * 32 + (kk & 31);
+          v = ld4(p.Wt + (long)c * p.ldb + (long)tap * p.N + n);
+        }
       }
       b_reg[i] = v;
     }
   };
 
   auto store_slab = [&](int buf) {
-    float* Ab = As + buf * BM * LDK;
-    float* Bb = Bs + buf * BN * LDK;
+    float* Ab = As + buf * BM * LDA;
+    float* Bb = Bs + buf * B_ELEMS;
+    const bool affine = p.a.s0 != nullptr;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-      const int f = tid + i * NT;
-      *reinterpret_cast<f32x4*>(Ab + (f >> 3) * LDK + 4 * (f & 7)) = row_src_apply<TWO>(a_raw[i], p.a);
+      f32x4 v = a_v0[i];
+      if (affine) {          // deferred prologue: BN affine (+ second source) + ReLU, zero where invalid
+        v = a_s0 * v + a_s2;
+        if (TWO) v += a_s1 * a_v1[i];
+        if (p.a.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (!((a_mask >> i) & 1u)) v = zero4;
+      }
+      *reinterpret_cast<f32x4*>(Ab + (a_row0 + i * RSTEP) * LDA + 4 * aq) = v;
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       const int f = tid + i * NT;
-      if (!p.b_kmajor) {
-        *reinterpret_cast<f32x4*>(Bb + (f >> 3) * LDK + 4 * (f & 7)) = b_reg[i];
+      if (!KMAJOR) {
+        *reinterpret_cast<f32x4*>(Bb + (f / Q) * LDA + 4 * (f % Q)) = b_reg[i];
       } else {
         const int kk = f / (BN / 4);
-        const int n = 4 * (f - kk * (BN / 4));
-        Bb[(n + 0) * LDK + kk] = b_reg[i].x;
-        Bb[(n + 1) * LDK + kk] = b_reg[i].y;
-        Bb[(n + 2) * LDK + kk] = b_reg[i].z;
-        Bb[(n + 3) * LDK + kk] = b_reg[i].w;
+        *reinterpret_cast<f32x4*>(Bb + kk * LDBK + 4 * (f - kk * (BN / 4))) = b_reg[i];
       }
     }
   };
@@ -194,15 +212,25 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const ConvGemmP
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto compute = [&](int buf) {
-    const float* Ab = As + buf * BM * LDK + (wm * TM * 32 + li) * LDK + 4 * lh;
-    const float* Bb = Bs + buf * BN * LDK + (wn * TN * 32 + li) * LDK + 4 * lh;
+    const float* Ab = As + buf * BM * LDA + (wm * TM * 32 + li) * LDA + ks * 32 + 4 * lh;
+    const float* Bb = Bs + buf * B_ELEMS;
 #pragma unroll
-    for (int s = 0; s < BK / 8; ++s) {
+    for (int s = 0; s < 4; ++s) {
       f32x4 af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = ld4(Ab + i * 32 * LDK + 8 * s);
+      for (int i = 0; i < TM; ++i) af[i] = ld4(Ab + i * 32 * LDA + 8 * s);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = ld4(Bb + j * 32 * LDK + 8 * s);
+      for (int j = 0; j < TN; ++j) {
+        if (!KMAJOR) {
+          bf[j] = ld4(Bb + ((wn * TN + j) * 32 + li) * LDA + ks * 32 + 4 * lh + 8 * s);
+        } else {
+          const float* q = Bb + (ks * 32 + 8 * s + 4 * lh) * LDBK + (wn * TN + j) * 32 + li;
+          bf[j].x = q[0];
+          bf[j].y = q[LDBK];
+          bf[j].z = q[2 * LDBK];
+          bf[j].w = q[3 * LDBK];
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -225,47 +253,78 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const ConvGemmP
     __syncthreads();
   }
 
-  // ---- epilogue -----------------------------------------------------------------------------
+  // ---- combine the K-split partial accumulators ---------------------------------------------
+  if (KS > 1) {
+    float* red = smem;   // [(KS-1)][WM*WN][TM*TN*16][64]
+    if (ks > 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            red[((((ks - 1) * (WM * WN) + wmn) * (TM * TN) + i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (ks == 0) {
+#pragma unroll
+      for (int k2 = 1; k2 < KS; ++k2)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              acc[i][j][r] += red[((((k2 - 1) * (WM * WN) + wmn) * (TM * TN) + i * TN + j) * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue (wave group ks == 0 holds the result) -----------------------------------------
   float st1[TN], st2[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) { st1[j] = 0.f; st2[j] = 0.f; }
+  if (ks == 0) {
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + (wn * TN + j) * 32 + li;
-    const bool colok = col < p.N;
-    float e0v = 1.f, e1v = 0.f;
-    if (colok && p.e0 != nullptr) e0v = p.e0[col];
-    if (colok && p.e1 != nullptr) e1v = p.e1[col];
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + li;
+      const bool colok = col < p.N;
+      float e0v = 1.f, e1v = 0.f;
+      if (colok && p.e0 != nullptr) e0v = p.e0[col];
+      if (colok && p.e1 != nullptr) e1v = p.e1[col];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (colok && row < p.M) {
-          float v = acc[i][j][r];
-          float ax = 0.f;
-          if (p.ep_mask) {
-            ax = p.aux[row * p.ldaux + col];
-            v = (fmaf(e0v, ax, e1v) > 0.f) ? v : 0.f;
+        for (int r = 0; r < 16; ++r) {
+          const long row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (colok && row < p.M) {
+            float v = acc[i][j][r];
+            float ax = 0.f;
+            if (p.ep_mask) {
+              ax = p.aux[row * p.ldaux + col];
+              v = (fmaf(e0v, ax, e1v) > 0.f) ? v : 0.f;
+            }
+            if (p.stats == 1) { st1[j] += v; st2[j] += v * v; }
+            else if (p.stats == 2) { st1[j] += v; st2[j] += v * ax; }
+            float* o = p.out + row * p.ldo + col;
+            if (p.ep_accum) *o += e0v * v; else *o = v;
           }
-          if (p.stats == 1) { st1[j] += v; st2[j] += v * v; }
-          else if (p.stats == 2) { st1[j] += v; st2[j] += v * ax; }
-          float* o = p.out + row * p.ldo + col;
-          if (p.ep_accum) *o += e0v * v; else *o = v;
         }
       }
     }
   }
   if (p.stats) {
-    float* red = smem;   // [WM][2][BN]; all waves are past the loop's last barrier
+    float* red = smem;   // [WM][2][BN]; every wave is past the last barrier above
+    if (ks == 0) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float a = st1[j] + __shfl_xor(st1[j], 32, 64);
-      float b = st2[j] + __shfl_xor(st2[j], 32, 64);
-      if (lh == 0) {
-        const int c = (wn * TN + j) * 32 + li;
-        red[(wm * 2 + 0) * BN + c] = a;
-        red[(wm * 2 + 1) * BN + c] = b;
+      for (int j = 0; j < TN; ++j) {
+        float a = st1[j] + __shfl_xor(st1[j], 32, 64);
+        float b = st2[j] + __shfl_xor(st2[j], 32, 64);
+        if (lh == 0) {
+          const int c = (wn * TN + j) * 32 + li;
+          red[(wm * 2 + 0) * BN + c] = a;
+          red[(wm * 2 + 1) * BN + c] = b;
+        }
       }
     }
     __syncthreads();
@@ -275,68 +334,61 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_gemm_kernel(const ConvGemmP
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < WM; ++w) s += red[(w * 2 + which) * BN + cc];
-        p.stats_out[((long)blockIdx.x * 2 + which) * p.N + n0 + cc] = s;
+        p.stats_out[((long)tile_x * 2 + which) * p.N + n0 + cc] = s;
       }
     }
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool TWO>
-void launch_cfg2(const ConvGemmParams& p, hipStream_t s) {
-  constexpr size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+template <int BM, int BN, int WM, int WN, int KS, bool TWO, bool KMAJOR>
+void launch_inst(const ConvGemmParams& p, hipStream_t s) {
+  constexpr int BKT = 32 * KS;
+  constexpr size_t b_elems = KMAJOR ? (size_t)BKT * (BN + 4) : (size_t)BN * (BKT + 4);
+  constexpr size_t lds = (2 * (size_t)BM * (BKT + 4) + 2 * b_elems) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, TWO>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, KS, TWO, KMAJOR>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.N + BN - 1) / BN));
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, TWO>), grid, dim3(64 * WM * WN), lds, s, p);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, KS, TWO, KMAJOR>), grid, dim3(64 * WM * WN * KS), lds, s, p);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int KS>
 void launch_cfg(const ConvGemmParams& p, hipStream_t s) {
-  if (p.a.X1 != nullptr) launch_cfg2<BM, BN, WM, WN, true>(p, s);
-  else launch_cfg2<BM, BN, WM, WN, false>(p, s);
+  const bool two = p.a.X1 != nullptr, km = p.b_kmajor != 0;
+  if (two && km) launch_inst<BM, BN, WM, WN, KS, true, true>(p, s);
+  else if (two) launch_inst<BM, BN, WM, WN, KS, true, false>(p, s);
+  else if (km) launch_inst<BM, BN, WM, WN, KS, false, true>(p, s);
+  else launch_inst<BM, BN, WM, WN, KS, false, false>(p, s);
+}
+
+int pick_bm(int M, int N, int force_bm) {
+  if (force_bm) return force_bm;
+  const long nt = N > 32 ? (N + 127) / 128 : 1;
+  if ((long)((M + 127) / 128) * nt >= 384) return 128;
+  if ((long)((M + 63) / 64) * nt >= 256) return 64;
+  return 32;
 }
 
 }  // namespace
 
 int conv_gemm_grid_x(int M, int N, int force_bm) {
-  int bm = force_bm;
-  if (bm == 0) {
-    if (N > 32) {
-      const long nt = (N + 127) / 128;
-      if ((long)((M + 127) / 128) * nt >= 384) bm = 128;
-      else if ((long)((M + 63) / 64) * nt >= 256) bm = 64;
-      else bm = 32;
-    } else {
-      if ((M + 127) / 128 >= 384) bm = 128;
-      else if ((M + 63) / 64 >= 256) bm = 64;
-      else bm = 32;
-    }
-  }
+  const int bm = pick_bm(M, N, force_bm);
   return (M + bm - 1) / bm;
 }
 
 void launch_conv_gemm(const ConvGemmParams& p, int force_bm, hipStream_t s) {
-  const int gx = conv_gemm_grid_x(p.M, p.N, force_bm);
-  const int bm = (p.M + gx - 1) / gx <= 32 ? 32 : ((p.M + gx - 1) / gx <= 64 ? 64 : 128);
-  // recompute bm exactly as conv_gemm_grid_x chose it
-  int chosen = force_bm;
-  if (chosen == 0) {
-    for (int cand : {128, 64, 32})
-      if ((p.M + cand - 1) / cand == gx) { chosen = cand; break; }
-  }
-  (void)bm;
+  const int bm = pick_bm(p.M, p.N, force_bm);
   if (p.N > 32) {
-    if (chosen == 128) launch_cfg<128, 128, 2, 2>(p, s);
-    else if (chosen == 64) launch_cfg<64, 128, 2, 2>(p, s);
-    else launch_cfg<32, 128, 1, 4>(p, s);
+    if (bm == 128) launch_cfg<128, 128, 2, 2, 1>(p, s);
+    else if (bm == 64) launch_cfg<64, 128, 2, 2, 1>(p, s);
+    else launch_cfg<32, 128, 1, 4, 2>(p, s);
   } else {
-    if (chosen == 128) launch_cfg<128, 32, 4, 1>(p, s);
-    else if (chosen == 64) launch_cfg<64, 32, 2, 1>(p, s);
-    else launch_cfg<32, 32, 1, 1>(p, s);
+    if (bm == 128) launch_cfg<128, 32, 4, 1, 1>(p, s);
+    else if (bm == 64) launch_cfg<64, 32, 2, 1, 2>(p, s);
+    else launch_cfg<32, 32, 1, 1, 4>(p, s);
   }
 }
 
