@@ -294,20 +294,30 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
       if (colok && p.e1 != nullptr) e1v = p.e1[col];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
+        // batch every global read of the tile (mask operand, old dBuf value) ahead of the stores:
+        // interleaved load/store pairs would serialise 16 dependent L2 round trips per tile
+        float axv[16], oldv[16];
+        const long rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const long row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const long row = rbase + (r & 3) + 8 * (r >> 2);
+          axv[r] = 0.f;
+          oldv[r] = 0.f;
+          if (colok && row < p.M) {
+            if (p.ep_mask) axv[r] = p.aux[row * p.ldaux + col];
+            if (p.ep_accum) oldv[r] = p.out[row * p.ldo + col];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long row = rbase + (r & 3) + 8 * (r >> 2);
           if (colok && row < p.M) {
             float v = acc[i][j][r];
-            float ax = 0.f;
-            if (p.ep_mask) {
-              ax = p.aux[row * p.ldaux + col];
-              v = (fmaf(e0v, ax, e1v) > 0.f) ? v : 0.f;
-            }
+            const float ax = axv[r];
+            if (p.ep_mask) v = (fmaf(e0v, ax, e1v) > 0.f) ? v : 0.f;
             if (p.stats == 1) { st1[j] += v; st2[j] += v * v; }
             else if (p.stats == 2) { st1[j] += v; st2[j] += v * ax; }
-            float* o = p.out + row * p.ldo + col;
-            if (p.ep_accum) *o += e0v * v; else *o = v;
+            p.out[row * p.ldo + col] = p.ep_accum ? fmaf(e0v, v, oldv[r]) : v;
           }
         }
       }
