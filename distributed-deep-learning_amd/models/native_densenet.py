@@ -112,28 +112,61 @@ class _BlockFn(torch.autograd.Function):
         nq = torch.zeros(Cf, **f32)           # deferred terms: dX = dBuf + nq * x + np
         np_ = torch.zeros(Cf, **f32)
         ones = unit.stage.ones
-        k = torch.empty(3, MID, **f32)
-        g2 = torch.empty(M, MID, **f32)
+        # Weight gradients feed nothing downstream, so they run on a side stream beside the
+        # data-gradient chain (parallel branches once the step is captured into a hipGraph).
+        # g2 / k are double-buffered by layer parity so a layer's 1x1 wgrad may still be reading
+        # them while the next layer's 3x3 dgrad runs.
+        side = unit.stage.side_stream if unit.stage.overlap_wgrad else None
+        main = torch.cuda.current_stream(buf.device)
+        k = torch.empty(2, 3, MID, **f32)
+        g2 = torch.empty(2, M, MID, **f32)
+        done = [None, None]
+        min_rows = unit.stage.wgrad_min_rows
         for l in range(L - 1, -1, -1):
             lay = unit.layers[l]
             C = C0 + GROWTH * l
+            par = l & 1
             sl = slice(C, C + GROWTH)
             dy, xs = d2d[:, sl], buf2d[:, sl]
             sc2, sh2 = bn2[l, 3], bn2[l, 4]
+            if side is not None:
+                if done[par] is not None:
+                    main.wait_event(done[par])
+                ev0 = torch.cuda.Event()
+                ev0.record(main)
             # 3x3 data gradient (+ ReLU/BN2 mask, sum g2, sum g2*h)
             st = ext.conv_gemm(dy, xs, ones[:GROWTH], nq[sl], np_[sl], False, M, H, W, 9, True,
-                               lay.w2, True, g2, True, False, h[l], sc2, sh2, 2, 0)
+                               lay.w2, True, g2[par], True, False, h[l], sc2, sh2, 2, 0)
             # 3x3 weight gradient
-            ext.conv_wgrad(dy, xs, ones[:GROWTH], nq[sl], np_[sl], h[l], sc2, sh2, True, M, H, W, 9,
-                           lay.gw2, unit.stage.wgrad_min_rows)
-            ext.bn_bwd_prep(st, float(M), bn2[l, 0], bn2[l, 2], sc2, lay.gg2, lay.gb2, k[0], k[1], k[2], MID, 0)
-            # 1x1 data gradient: dh = k0*g2 + k1*h + k2 on the fly; epilogue: mask, dBuf += sc1*g1, sums
-            st1 = ext.conv_gemm(g2, h[l], k[0], k[1], k[2], False, M, H, W, 1, False,
-                                lay.w1, True, d2d[:, :C], True, True, buf2d[:, :C], sc1[l], sh1[l], 2, 0)
+            if side is not None:
+                side.wait_event(ev0)
+                with torch.cuda.stream(side):
+                    ext.conv_wgrad(dy, xs, ones[:GROWTH], nq[sl], np_[sl], h[l], sc2, sh2, True, M, H, W, 9,
+                                   lay.gw2, min_rows)
+            else:
+                ext.conv_wgrad(dy, xs, ones[:GROWTH], nq[sl], np_[sl], h[l], sc2, sh2, True, M, H, W, 9,
+                               lay.gw2, min_rows)
+            ext.bn_bwd_prep(st, float(M), bn2[l, 0], bn2[l, 2], sc2, lay.gg2, lay.gb2,
+                            k[par, 0], k[par, 1], k[par, 2], MID, 0)
             # 1x1 weight gradient (activation re-normalised on the fly)
-            ext.conv_wgrad(g2, h[l], k[0], k[1], k[2], buf2d[:, :C], sc1[l], sh1[l], True, M, H, W, 1,
-                           lay.gw1, unit.stage.wgrad_min_rows)
+            if side is not None:
+                ev1 = torch.cuda.Event()
+                ev1.record(main)
+                side.wait_event(ev1)
+                with torch.cuda.stream(side):
+                    ext.conv_wgrad(g2[par], h[l], k[par, 0], k[par, 1], k[par, 2], buf2d[:, :C], sc1[l], sh1[l],
+                                   True, M, H, W, 1, lay.gw1, min_rows)
+                    done[par] = torch.cuda.Event()
+                    done[par].record(side)
+            else:
+                ext.conv_wgrad(g2[par], h[l], k[par, 0], k[par, 1], k[par, 2], buf2d[:, :C], sc1[l], sh1[l],
+                               True, M, H, W, 1, lay.gw1, min_rows)
+            # 1x1 data gradient: dh = k0*g2 + k1*h + k2 on the fly; epilogue: mask, dBuf += sc1*g1, sums
+            st1 = ext.conv_gemm(g2[par], h[l], k[par, 0], k[par, 1], k[par, 2], False, M, H, W, 1, False,
+                                lay.w1, True, d2d[:, :C], True, True, buf2d[:, :C], sc1[l], sh1[l], 2, 0)
             ext.bn_bwd_prep(st1, float(M), stats[0], stats[2], sc1[l], lay.gg1, lay.gb1, None, nq, np_, C, 1)
+        if side is not None:
+            main.wait_stream(side)
         dx = torch.empty(B, H, W, C0, **f32)
         ext.rows_op(4, M, d2d[:, :C0], buf2d[:, :C0], nq, np_, dx.view(M, C0), H, W, False)
         unit.stage._unit_grads_ready(unit)
@@ -375,6 +408,8 @@ class NativeDenseNetStage(nn.Module):
         self.param_index: Dict[str, int] = {n: i for i, n in enumerate(self.arena.names)}
         self._buffers_by_name = dict(self.named_buffers())
         self.anchor = torch.zeros(1, device=device, requires_grad=True)   # keeps every unit in the graph
+        self.side_stream = torch.cuda.Stream(device)
+        self.overlap_wgrad = True
         self.ones = torch.ones(1024, device=device)
         self._grad_ready_cb = None
         self.unit_objs = []

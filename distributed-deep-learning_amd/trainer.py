@@ -36,6 +36,7 @@ from .parallel.dp import DataParallelEngine
 from .parallel.pp import SCHEDULES, PipelineStage
 from .profiler import StepProfiler
 from .utils.arena import FlatArena, reverse_named_parameters
+from .utils.graph import GraphedTrainStep
 
 
 def set_seed(seed: int) -> None:
@@ -118,20 +119,13 @@ class SingleStrategy(Strategy):
         self.arena = _arena_for(self.model, self.device, cfg.bucket_mb, 1)
         self.optimizer = self._make_optimizer(self.arena)
         self.global_rank = self.local_rank = 0          # single.py:269 hard-codes 0,0
+        # zero_grad -> forward -> fused CE -> backward -> fused Adam (reference: single.py:136-154),
+        # replayed as one hipGraph launch after two eager warm-up steps
+        self._step = GraphedTrainStep(self.model, self.optimizer, None, self.profiler,
+                                      enabled=cfg.hip_graph and self.device.type == "cuda")
 
     def train_step(self, x, y, batch_size):
-        fused = getattr(self.model, "train_step", None)
-        if fused is not None:
-            return fused(x, y, self.optimizer, profiler=self.profiler)
-        tok = self.profiler.begin("step")
-        self.optimizer.zero_grad()
-        out = self.model(x)
-        loss, preds = ops.cross_entropy_with_preds(out, y)
-        loss.backward()
-        self.optimizer.step()
-        self.profiler.end(tok)
-        self.profiler.step_done()
-        return loss.detach(), out.detach(), preds
+        return self._step(x, y)
 
     @torch.no_grad()
     def eval_step(self, x, y, batch_size):
@@ -154,31 +148,17 @@ class DDPStrategy(Strategy):
         self.optimizer = self._make_optimizer(self.arena, shard)
         self.dp_rank, self.dp_size = self.dp.rank, self.dp.world
         self.is_logger = ctx.rank == 0
+        self._step = GraphedTrainStep(self.model, self.optimizer, self.dp, self.profiler,
+                                      enabled=cfg.hip_graph and self.device.type == "cuda")
 
     @staticmethod
     def _native_kw(cfg, world):
         return dict(bucket_mb=cfg.bucket_mb, dp_world=world) if cfg.impl != "torch" else {}
 
     def train_step(self, x, y, batch_size):
-        fused = getattr(self.model, "train_step", None)
-        if fused is not None:
-            return fused(x, y, self.optimizer, dp=self.dp, profiler=self.profiler)
-        prof = self.profiler
-        tok = prof.begin("step")
-        self.optimizer.zero_grad()
-        self.dp.pre_forward()
-        self.dp.arm(True)
-        out = self.model(x)
-        loss, preds = ops.cross_entropy_with_preds(out, y)
-        loss.backward()                     # hooks launch bucket collectives as grads complete
-        tok2 = prof.begin("exposed_comm")
-        self.dp.finish_grad_sync()
-        prof.end(tok2)
-        self.optimizer.step()
-        self.dp.post_step()
-        prof.end(tok)
-        prof.step_done()
-        return loss.detach(), out.detach(), preds
+        # eager form: buffer broadcast -> forward -> backward (bucket collectives launched by the
+        # gradient-ready hooks, overlapped) -> wait -> Adam (reference: ddp.py:150-170)
+        return self._step(x, y)
 
     @torch.no_grad()
     def eval_step(self, x, y, batch_size):
