@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of single native kernels on representative DenseNet-121 shapes (B=30 by default):
+event-timed, reports achieved TFLOP/s.  `--only NAME` restricts to one case (for rocprofv3 --pmc)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from ddl import ops
+from ddl.models.native_densenet import NativeDenseNetStage
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=30)
+ap.add_argument("--only", default=None)
+ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--bm", type=int, default=0)
+a = ap.parse_args()
+ext = ops.require_ext()
+dev = torch.device("cuda", 0)
+B = a.batch
+torch.manual_seed(0)
+
+
+def timeit(fn, iters=a.iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3      # us
+
+
+cases = []
+
+
+def case(name, flops):
+    def deco(fn):
+        cases.append((name, flops, fn))
+        return fn
+    return deco
+
+
+def mk(H, C, Cf):
+    M = B * H * H
+    buf = torch.randn(M, Cf, device=dev)
+    return M, buf
+
+
+for (blk, H, Cl, Cf) in [("b1", 56, 160, 256), ("b2", 28, 320, 512), ("b3", 14, 640, 1024), ("b4", 7, 768, 1024)]:
+    M, buf = mk(H, Cl, Cf)
+    sc, sh = torch.rand(Cf, device=dev) + 0.5, torch.randn(Cf, device=dev)
+    w1 = torch.randn(128, Cl, device=dev) * 0.05
+    w2 = torch.randn(32, 9 * 128, device=dev) * 0.05
+    h = torch.randn(M, 128, device=dev)
+    g2 = torch.randn(M, 128, device=dev)
+    out128 = torch.empty(M, 128, device=dev)
+    dbuf = torch.randn(M, Cf, device=dev)
+    ones = torch.ones(1024, device=dev)
+    k = torch.randn(3, 128, device=dev) * 0.1
+    gw1 = torch.zeros(128, Cl, device=dev)
+    gw2 = torch.zeros(32, 9 * 128, device=dev)
+
+    def f1(M=M, buf=buf, Cl=Cl, sc=sc, sh=sh, w1=w1, out=out128, H=H):
+        ext.conv_gemm(buf[:, :Cl], None, sc, None, sh, True, M, H, H, 1, False, w1, False, out, False, False,
+                      None, None, None, 1, a.bm)
+    cases.append((f"{blk}_fwd1x1_K{Cl}", 2.0 * M * Cl * 128, f1))
+
+    def f2(M=M, h=h, sc=sc, sh=sh, w2=w2, buf=buf, Cl=Cl, H=H):
+        ext.conv_gemm(h, None, sc, None, sh, True, M, H, H, 9, False, w2, False, buf[:, Cl:Cl + 32], False, False,
+                      None, None, None, 1, a.bm)
+    cases.append((f"{blk}_fwd3x3", 2.0 * M * 1152 * 32, f2))
+
+    def f3(M=M, dbuf=dbuf, buf=buf, Cl=Cl, ones=ones, sc=sc, sh=sh, w2=w2, g2=g2, h=h, H=H):
+        ext.conv_gemm(dbuf[:, Cl:Cl + 32], buf[:, Cl:Cl + 32], ones[:32], sc[:32], sh[:32], False, M, H, H, 9, True,
+                      w2, True, g2, True, False, h, sc, sh, 2, a.bm)
+    cases.append((f"{blk}_dgrad3x3", 2.0 * M * 1152 * 32, f3))
+
+    def f4(M=M, g2=g2, h=h, k=k, w1=w1, dbuf=dbuf, buf=buf, Cl=Cl, sc=sc, sh=sh, H=H):
+        ext.conv_gemm(g2, h, k[0], k[1], k[2], False, M, H, H, 1, False, w1, True, dbuf[:, :Cl], True, True,
+                      buf[:, :Cl], sc, sh, 2, a.bm)
+    cases.append((f"{blk}_dgrad1x1_N{Cl}", 2.0 * M * Cl * 128, f4))
+
+    def f5(M=M, g2=g2, h=h, k=k, buf=buf, Cl=Cl, sc=sc, sh=sh, gw1=gw1, H=H):
+        ext.conv_wgrad(g2, h, k[0], k[1], k[2], buf[:, :Cl], sc, sh, True, M, H, H, 1, gw1, 64)
+    cases.append((f"{blk}_wgrad1x1_C{Cl}", 2.0 * M * Cl * 128, f5))
+
+    def f6(M=M, dbuf=dbuf, buf=buf, Cl=Cl, ones=ones, sc=sc, sh=sh, h=h, gw2=gw2, H=H):
+        ext.conv_wgrad(dbuf[:, Cl:Cl + 32], buf[:, Cl:Cl + 32], ones[:32], sc[:32], sh[:32], h, sc, sh, True, M, H, H,
+                       9, gw2, 64)
+    cases.append((f"{blk}_wgrad3x3", 2.0 * M * 1152 * 32, f6))
+
+for name, flops, fn in cases:
+    if a.only and a.only != name:
+        continue
+    us = timeit(fn)
+    print(f"{name:24s} {us:9.1f} us  {flops / us / 1e6:7.1f} TFLOP/s", flush=True)

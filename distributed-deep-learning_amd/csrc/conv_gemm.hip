@@ -232,12 +232,14 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
         }
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int j = 0; j < TN; ++j) {
+        if (n0 + (wn * TN + j) * 32 >= p.N) continue;      // wave-uniform: sub-tile beyond N (N % 128 != 0)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
+          for (int i = 0; i < TM; ++i)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+      }
     }
   };
 
@@ -374,11 +376,19 @@ void launch_cfg(const ConvGemmParams& p, hipStream_t s) {
   else launch_inst<BM, BN, WM, WN, KS, false, false>(p, s);
 }
 
+// Row-tile height.  Measured on MI355X (bench/kernel_bench.py, B=30 shapes): for the 128-column
+// configs 64-row tiles beat 128-row tiles up to ~1500 row tiles (finer granularity = smaller tail
+// when tiles are dealt over 512 resident workgroup slots); the 32-column 3x3 forward prefers 128.
 int pick_bm(int M, int N, int force_bm) {
   if (force_bm) return force_bm;
-  const long nt = N > 32 ? (N + 127) / 128 : 1;
-  if ((long)((M + 127) / 128) * nt >= 384) return 128;
-  if ((long)((M + 63) / 64) * nt >= 256) return 64;
+  if (N > 32) {
+    const long nt = (N + 127) / 128;
+    if ((long)((M + 63) / 64) * nt >= 8192) return 128;
+    if ((long)((M + 63) / 64) * nt >= 256) return 64;
+    return 32;
+  }
+  if ((M + 127) / 128 >= 384) return 128;
+  if ((M + 63) / 64 >= 256) return 64;
   return 32;
 }
 
