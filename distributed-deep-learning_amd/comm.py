@@ -81,10 +81,8 @@ def init(backend: str = "auto", device: str = "auto", timeout_s: int = 600,
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        kw = {}
-        if backend == "nccl":
-            kw["device_id"] = dev   # eager RCCL communicator creation, binds the PG to this GPU
-        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=timeout_s), **kw)
+        # lazy RCCL communicator creation (first collective) - the most travelled c10d path
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=timeout_s))
     return CommContext(rank, world, local_rank, dev, backend)
 
 
@@ -187,11 +185,25 @@ def _is_gloo(group) -> bool:
     return backend_of(group) == "gloo"
 
 
+def _host_staged(group, t: torch.Tensor) -> bool:
+    """gloo (the test transport) moves GPU tensors through host memory: this is what lets the
+    multi-rank DP / PP logic run with the native engine on ONE GPU (ranks share the device)."""
+    return t.is_cuda and _is_gloo(group)
+
+
 def all_reduce(t: torch.Tensor, op: str = "sum", group=None, async_op: bool = False):
     """In-place all-reduce; ``op`` in {sum, avg, max}.  AVG is native on RCCL, emulated on gloo."""
     if get_world_size(group) == 1 and not is_dist():
         return None
     _log("all_reduce", t, group)
+    if _host_staged(group, t):
+        h = t.detach().cpu()
+        dist.all_reduce(h, {"sum": dist.ReduceOp.SUM, "avg": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX,
+                            "min": dist.ReduceOp.MIN}[op], group=group)
+        if op == "avg":
+            h.div_(get_world_size(group))
+        t.copy_(h)
+        return None
     if op == "avg":
         if _is_gloo(group):
             w = dist.all_reduce(t, dist.ReduceOp.SUM, group=group, async_op=False)
@@ -207,6 +219,11 @@ def broadcast(t: torch.Tensor, src: int, group=None, async_op: bool = False):
     if not is_dist():
         return None
     _log("broadcast", t, group)
+    if _host_staged(group, t):
+        h = t.detach().cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+        return None
     return dist.broadcast(t, src=src, group=group, async_op=async_op)
 
 
@@ -218,6 +235,11 @@ def all_gather_flat(t: torch.Tensor, group=None) -> torch.Tensor:
         return t
     t = t.contiguous()
     _log("all_gather", t, group)
+    if _host_staged(group, t):
+        h = t.detach().cpu()
+        out = torch.empty((w * h.shape[0],) + tuple(h.shape[1:]), dtype=h.dtype)
+        dist.all_gather_into_tensor(out, h, group=group)
+        return out.to(t.device)
     out = torch.empty((w * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t, group=group)
     return out
@@ -227,6 +249,11 @@ def all_gather_into(out: torch.Tensor, shard: torch.Tensor, group=None, async_op
     """``out`` (W*n) <- concat of every rank's ``shard`` (n).  In-place form allowed
     (``shard`` a view of ``out`` at this rank's offset), as RCCL defines it."""
     _log("all_gather", shard, group)
+    if _host_staged(group, out):
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h, shard.detach().cpu(), group=group)
+        out.copy_(h)
+        return None
     if _is_gloo(group):
         # gloo: out-of-place only
         tmp = shard.clone()
@@ -242,6 +269,15 @@ def reduce_scatter_into(shard: torch.Tensor, full: torch.Tensor, op: str = "sum"
     emulate with all-reduce + slice (test transport only)."""
     _log("reduce_scatter", full, group)
     w = get_world_size(group)
+    if _host_staged(group, full):
+        h = full.detach().cpu()
+        dist.all_reduce(h, dist.ReduceOp.SUM, group=group)
+        r, n = get_rank(group), shard.numel()
+        piece = h[r * n:(r + 1) * n]
+        if op == "avg":
+            piece = piece / w
+        shard.copy_(piece)
+        return None
     if _is_gloo(group):
         dist.all_reduce(full, dist.ReduceOp.SUM, group=group)
         r = get_rank(group)

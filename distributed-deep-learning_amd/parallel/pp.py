@@ -146,9 +146,29 @@ class PipelineStage:
             self.inputs.pop(i, None)
 
 
+class _StagedRecv:
+    """gloo (test transport) cannot move GPU tensors: receive into host memory, copy up on wait."""
+
+    def __init__(self, work, host: torch.Tensor, dev: torch.Tensor) -> None:
+        self.work, self.host, self.dev = work, host, dev
+
+    def wait(self) -> None:
+        self.work.wait()
+        self.dev.copy_(self.host)
+
+
 def _batch_p2p(ops: List[dist.P2POp]):
     if not ops:
         return []
+    if ops[0].tensor.is_cuda and comm.backend_of(ops[0].group) == "gloo":
+        works = []
+        for op in ops:
+            if op.op is dist.isend:
+                works.append(dist.isend(op.tensor.detach().cpu(), op.peer, group=op.group))
+            else:
+                host = torch.empty(op.tensor.shape, dtype=op.tensor.dtype)
+                works.append(_StagedRecv(dist.irecv(host, op.peer, group=op.group), host, op.tensor))
+        return works
     return dist.batch_isend_irecv(ops)
 
 
