@@ -27,7 +27,8 @@ for r in sel:
                                             "kmaj" if m.group(7) in ("true", "1") else "nmaj")
     else:
         m = re.search(r"(wgrad\dx\d_kernel|slab_reduce_kernel|bn_prep_kernel|bn_bwd_prep_kernel|rows_op_kernel|"
-                      r"adam_flat_kernel|ce_fwd_bwd_kernel|normalize_u8_kernel|bnrelu_gap_fwd_kernel)", n)
+                      r"adam_flat_kernel|ce_fwd_bwd_kernel|normalize_u8_kernel|bnrelu_gap_fwd_kernel|stem_\w+_kernel|"
+                      r"linear_\w+_kernel|adam_inc_step_kernel)", n)
         n = m.group(1) if m else re.sub(r"\(.*", "", n)[:60]
     if detail:
         n += " grid%s" % (g,)

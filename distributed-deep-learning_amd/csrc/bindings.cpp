@@ -64,6 +64,7 @@ void adam_step(at::Tensor p, at::Tensor g, at::Tensor m, at::Tensor v, at::Tenso
 }  // namespace
 
 void register_conv_ops(pybind11::module_& m);   // conv_bindings.cpp
+void register_stem_ops(pybind11::module_& m);   // stem_bindings.cpp
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "hand-written gfx950 (MI355X) kernels of the ddl framework";
@@ -71,4 +72,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("ce_fwd_bwd", &ce_fwd_bwd, "fused softmax+CE loss, dlogits, argmax");
   m.def("adam_step", &adam_step, "flat fused Adam (+zero_grad)");
   register_conv_ops(m);
+  register_stem_ops(m);
 }

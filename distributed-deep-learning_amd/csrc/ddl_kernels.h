@@ -46,4 +46,23 @@ int launch_rows_op(int mode, long M, int C, const float* in, int ldi, const floa
                    hipStream_t s);
 void launch_bnrelu_gap_fwd(const float* x, int ldx, int B, int HW, const float* sc, const float* sh,
                            float* pooled, int C, hipStream_t s);
+// ---- stem_kernels.hip ------------------------------------------------------------------
+void launch_stem_pack(const void* in, bool is_u8, float* out, int B, int H, int W, hipStream_t s);
+void launch_stem_pack_weight(const float* w /*[64,3,7,7]*/, float* wp /*[64,224]*/, hipStream_t s);
+int stem_conv_grid(long M0);                      // row tiles (= rows of the statistics table)
+void launch_stem_conv_fwd(const float* xp, const float* wp, float* y0, float* stats, long M0, int H, int W,
+                          int H0, int W0, hipStream_t s);
+void launch_stem_pool_fwd(const float* y0, const float* sc, const float* sh, float* p, uint8_t* idx, int B,
+                          int H0, int W0, int H1, int W1, hipStream_t s);
+int stem_pool_bwd_grid(long M0);                  // rows of its statistics table
+void launch_stem_pool_bwd(const float* y0, const float* sc, const float* sh, const float* dp, const uint8_t* idx,
+                          float* g0, float* stats, int B, int H0, int W0, int H1, int W1, hipStream_t s);
+int stem_wgrad_slabs(int B, int H0, int W0);      // slabs [S][64][224] the caller must provide
+void launch_stem_wgrad(const float* g0, const float* y0, const float* k0, const float* k1, const float* k2,
+                       const float* xp, float* slabs, float* dW /*[64,3,7,7], +=*/, int B, int H, int W, int H0,
+                       int W0, hipStream_t s);
+void launch_linear_fwd(const float* x, const float* w, const float* bias, float* out, int B, int K, int N,
+                       hipStream_t s);
+void launch_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* dW, float* db, int B,
+                       int K, int N, hipStream_t s);
 }  // namespace ddl

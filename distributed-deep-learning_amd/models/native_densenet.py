@@ -24,8 +24,9 @@ Same architecture, parameter names and numerics (fp32) as ``ddl.models.densenet`
   units       every unit (stem, block, transition, head-pool) is ONE autograd node, so pipeline
               stages and the data-parallel reducer see ~10 nodes instead of ~600.
 
-The stem (7x7 conv + BN + ReLU + max-pool, 4% of the FLOPs) and the 1024->5 classifier GEMM
-still go through PyTorch-ROCm library ops (MIOpen / rocBLAS); everything else is native.
+Nothing in the training step goes through MIOpen / rocBLAS: the stem (7x7/2 conv as an MFMA
+implicit GEMM over an NHWC4 repack, BN + ReLU + max-pool fused) and the 1024->5 classifier are
+native kernels too (csrc/stem_kernels.hip).
 
 Weight layouts (converted at the checkpoint boundary by ``ddl_export_tensor`` /
 ``ddl_import_tensor``, so checkpoints stay in the torchvision layout - SURVEY 5.4):
@@ -38,7 +39,6 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import ops
 from ..utils.arena import FlatArena, FlatBuffers, reverse_named_parameters
@@ -293,9 +293,9 @@ class TransitionUnit:
 
 
 # ======================================================================================
-# head: norm5 + ReLU + global average pool (native) -> Linear (rocBLAS via torch)
+# head: norm5 + ReLU + global average pool + Linear(1024 -> classes), all native, ONE autograd node
 # ======================================================================================
-class _HeadPoolFn(torch.autograd.Function):
+class _HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, buf: torch.Tensor, anchor: torch.Tensor, unit: "HeadUnit", in_stats):
         ext = _ext()
@@ -312,23 +312,25 @@ class _HeadPoolFn(torch.autograd.Function):
         ext.bn_prep(None, 0, 0, float(M), stats[0], stats[1], stats[2], unit.g, unit.b, unit.rm, unit.rv,
                     ss[0], ss[1], C, BN_MOMENTUM, BN_EPS, train)
         pooled = ext.bnrelu_gap_fwd(buf2d, B, H * W, ss[0], ss[1])
+        logits = ext.linear_fwd(pooled, unit.cw, unit.cb)
         ctx.unit = unit
         ctx.geom = (B, H, W, C)
-        ctx.save_for_backward(buf, stats, ss)
-        return pooled
+        ctx.save_for_backward(buf, stats, ss, pooled)
+        return logits
 
     @staticmethod
-    def backward(ctx, dpooled: torch.Tensor):
+    def backward(ctx, dlogits: torch.Tensor):
         ext = _ext()
         unit = ctx.unit
-        buf, stats, ss = ctx.saved_tensors
+        buf, stats, ss, pooled = ctx.saved_tensors
         B, H, W, C = ctx.geom
         M = B * H * W
         f32 = dict(dtype=torch.float32, device=buf.device)
         buf2d = buf.view(M, C)
+        dpooled = ext.linear_bwd(dlogits.contiguous(), pooled, unit.cw, unit.gcw, unit.gcb)
         dbuf = torch.empty(B, H, W, C, **f32)
         d2d = dbuf.view(M, C)
-        st = ext.rows_op(3, M, dpooled.contiguous(), buf2d, ss[0], ss[1], d2d, H, W, True)
+        st = ext.rows_op(3, M, dpooled, buf2d, ss[0], ss[1], d2d, H, W, True)
         k = torch.empty(3, C, **f32)
         ext.bn_bwd_prep(st, float(M), stats[0], stats[2], ss[0], unit.gg, unit.gb, k[0], k[1], k[2], C, 0)
         ext.rows_op(4, M, d2d, buf2d, k[1], k[2], d2d, H, W, False)
@@ -345,31 +347,57 @@ class HeadUnit:
         st = self.stage
         self.g, self.gg = st.pv("features.norm5.weight")
         self.b, self.gb = st.pv("features.norm5.bias")
+        self.cw, self.gcw = st.pv("classifier.weight")
+        self.cb, self.gcb = st.pv("classifier.bias")
         self.rm, self.rv = st.bv("features.norm5.running_mean"), st.bv("features.norm5.running_var")
-        self.param_names = ["features.norm5.weight", "features.norm5.bias"]
+        self.param_names = ["features.norm5.weight", "features.norm5.bias", "classifier.weight", "classifier.bias"]
 
     def __call__(self, x, in_stats):
-        pooled = _HeadPoolFn.apply(x, self.stage.anchor, self, in_stats)
-        cls = self.stage.classifier
-        return F.linear(pooled, cls.weight, cls.bias), None      # autograd + rocBLAS; grads land in the arena views
+        return _HeadFn.apply(x, self.stage.anchor, self, in_stats), None
+
+
+# ======================================================================================
+# stem: conv0 7x7/2 (fp32 MFMA implicit GEMM over an NHWC4 repack of the image batch, norm0
+# statistics in its epilogue) -> BN + ReLU + max-pool 3x3/2 in one pass; backward = pool/ReLU/BN
+# masks in one pass + conv0 weight gradient (csrc/stem_kernels.hip).  ONE autograd node.
+# ======================================================================================
+class _StemFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, anchor: torch.Tensor, unit: "StemUnit"):
+        ext = _ext()
+        train = unit.stage.training
+        pooled, xp, y0, stats, ss, idx = ext.stem_fwd(x.contiguous(), unit.w, unit.g, unit.b, unit.rm, unit.rv,
+                                                      train, BN_MOMENTUM, BN_EPS)
+        ctx.unit = unit
+        ctx.save_for_backward(xp, y0, stats, ss, idx)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dp: torch.Tensor):
+        unit = ctx.unit
+        xp, y0, stats, ss, idx = ctx.saved_tensors
+        _ext().stem_bwd(dp.contiguous(), xp, y0, stats, ss, idx, unit.gw, unit.gg, unit.gb)
+        unit.stage._unit_grads_ready(unit)
+        return None, None, None
 
 
 class StemUnit:
-    """conv0 7x7/2 + norm0 + ReLU + maxpool 3x3/2 through PyTorch-ROCm (MIOpen) - scaffolding for the
-    4% of the FLOPs that are not yet native; output re-laid-out to NHWC for the first dense block."""
-
     def __init__(self, stage: "NativeDenseNetStage") -> None:
         self.stage, self.name = stage, "stem"
         self.param_names: List[str] = []
 
     def bind(self) -> None:
-        pass
+        st = self.stage
+        self.w, self.gw = st.pv("features.conv0.weight")          # torch layout [64,3,7,7]
+        self.g, self.gg = st.pv("features.norm0.weight")
+        self.b, self.gb = st.pv("features.norm0.bias")
+        self.rm, self.rv = st.bv("features.norm0.running_mean"), st.bv("features.norm0.running_var")
+        self.param_names = ["features.conv0.weight", "features.norm0.weight", "features.norm0.bias"]
 
     def __call__(self, x, in_stats):
-        f = self.stage.features
-        x = ops.normalize_input(x, channels_last=False) if x.dtype == torch.uint8 else x
-        y = f.pool0(F.relu(f.norm0(f.conv0(x)), inplace=True))
-        return y.permute(0, 2, 3, 1).contiguous(), None
+        if x.dtype not in (torch.uint8, torch.float32):
+            x = x.float()
+        return _StemFn.apply(x, self.stage.anchor, self), None
 
 
 # ======================================================================================
@@ -492,8 +520,7 @@ class NativeDenseNetStage(nn.Module):
         for u in self.unit_objs:
             x, stats = u(x, stats)
         if self.training:
-            # num_batches_tracked of the natively handled BN layers (+1 per forward, one launch);
-            # norm0 goes through F.batch_norm, which bumps its own counter
+            # num_batches_tracked of every BN layer (+1 per forward, one launch over the flat buffer)
             self._bump_counters()
         return x
 
@@ -502,8 +529,6 @@ class NativeDenseNetStage(nn.Module):
         if fi.numel() == 0:
             return
         fi.add_(1)
-        if self.is_first:
-            self.features.norm0.num_batches_tracked.sub_(1)
 
     def output_shape(self, in_shape):
         """NHWC output shape for an NCHW (first stage) / NHWC input shape."""

@@ -162,6 +162,51 @@ def test_head_fwd_bwd(dev):
     _compare_unit(dev, ("denseblock4", "head"), (4, 512, 7, 7))
 
 
+@pytest.mark.parametrize("shape", [(3, 3, 64, 64), (2, 3, 70, 90), (2, 3, 224, 224)])
+def test_stem_fwd_bwd(dev, shape):
+    """conv0 7x7/2 (MFMA over the NHWC4 repack) + norm0 + ReLU + maxpool and their backward; odd
+    output sizes (35x45) exercise partial 16-pixel segments and pooling-window clipping."""
+    _compare_unit(dev, ("stem",), shape)
+
+
+def test_stem_uint8_and_constant_regions(dev):
+    """uint8 input (/255 fused into the repack) with large constant regions: every pooling window
+    there is a tie, which torch resolves to the FIRST maximum - the recorded-argmax backward must
+    route the gradient identically (an equality test against the pooled value would over-count)."""
+    ref = _ref_stage(("stem",), dev)
+    nat = _native_from(ref, ("stem",), dev)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(0, 256, (2, 3, 96, 96), dtype=torch.uint8, generator=g)
+    x[:, :, :40, :] = 7                       # flat background, like the black border of a fundus image
+    x[:, :, :, 70:] = 200
+    x = x.to(dev)
+    ref.train(); nat.train()
+    yr = ref(x)
+    yn = nat(x)
+    torch.testing.assert_close(yn.permute(0, 3, 1, 2), yr, rtol=1e-4, atol=1e-4)
+    gy = _rand(*yr.shape, dev=dev, seed=9)
+    yr.backward(gy)
+    nat.arena.zero_grad()
+    yn.backward(gy.permute(0, 2, 3, 1).contiguous())
+    gr = dict(ref.named_parameters())
+    for name, p in nat.named_parameters():
+        assert _relerr(p.grad, gr[name].grad) < 2e-4, name
+
+
+def test_classifier_kernels(dev):
+    from ddl import ops
+    ext = ops.require_ext()
+    x, w, b = _rand(30, 1024, dev=dev, seed=1), _rand(5, 1024, dev=dev, seed=2, scale=0.05), _rand(5, dev=dev, seed=3)
+    out = ext.linear_fwd(x, w, b)
+    torch.testing.assert_close(out.double(), x.double() @ w.double().t() + b.double(), rtol=1e-5, atol=1e-5)
+    dy = _rand(30, 5, dev=dev, seed=4)
+    dW, db = torch.ones_like(w), torch.ones_like(b)          # accumulate semantics
+    dx = ext.linear_bwd(dy, x, w, dW, db)
+    torch.testing.assert_close(dx.double(), dy.double() @ w.double(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dW.double(), 1 + dy.double().t() @ x.double(), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(db.double(), 1 + dy.double().sum(0), rtol=1e-5, atol=1e-5)
+
+
 def test_full_model_fwd_bwd(dev):
     from ddl.models.densenet import UNIT_NAMES
     # 121 BN layers deep on a 2-image batch: chaotic (torch fp32 itself is ~1e-3..1e-2 from fp64 here),
