@@ -1,0 +1,64 @@
+"""ddl.analysis reproduces the reference notebook's three tables (ipynb/main.ipynb) from logs in
+the reference CSV schema; the pinned numbers are the notebook's own published outputs."""
+import os
+
+import pytest
+
+from ddl import analysis
+from ddl.metrics import CsvMetricLogger
+
+
+def _write_job(log_dir, job, values_by_metric):
+    lg = CsvMetricLogger(str(log_dir), job, 0, 0)
+    for metric, vals in values_by_metric.items():
+        for epoch, v in enumerate(vals):
+            lg.log(metric, v, epoch)
+    return lg
+
+
+def test_epoch_time_table_and_speedup(tmp_path):
+    # per-job means published in ipynb/main.ipynb:259,268,273
+    _write_job(tmp_path, "single-gg6r7plwk2b4vd", {"epoch_time": [90.0, 91.54]})
+    _write_job(tmp_path, "ddp-j0ldqsn0pdpwfc", {"epoch_time": [61.0, 61.28]})
+    _write_job(tmp_path, "pp-kw02jgxb3h7mwd", {"epoch_time": [111.21]})
+    t = analysis.epoch_time_by_job(str(tmp_path), samples_per_epoch=2400).set_index("job_id")
+    assert t.loc["single-gg6r7plwk2b4vd", "time"] == pytest.approx(90.77)
+    assert t.loc["ddp-j0ldqsn0pdpwfc", "samples_per_s"] == pytest.approx(2400 / 61.14)
+    assert t.loc["pp-kw02jgxb3h7mwd", "strategy"] == "pp"
+    s = analysis.speedup_vs_single(t.reset_index()).set_index("strategy")
+    assert s.loc["ddp", "speedup_vs_single"] == pytest.approx(90.77 / 61.14)      # 1.48x
+    assert s.loc["pp", "speedup_vs_single"] == pytest.approx(90.77 / 111.21)      # 0.82x
+
+
+def test_final_metrics_by_strategy(tmp_path):
+    for i, (acc, f1) in enumerate([(0.70, 0.71), (0.80, 0.79)]):
+        _write_job(tmp_path, f"ddp-job{i}", {m: [0.1, v] for m, v in
+                                            zip(analysis.QUALITY_METRICS, (0.5, 0.9, 1.2, acc, f1))})
+    _write_job(tmp_path, "single-job0", {m: [0.1, 0.3] for m in analysis.QUALITY_METRICS})
+    df = analysis.final_metrics_by_strategy(str(tmp_path), epoch=1).set_index("strategy")
+    assert df.loc["ddp", "val_accuracy"] == pytest.approx(0.75)
+    assert df.loc["ddp", "weighted_f1"] == pytest.approx(0.75)
+    assert df.loc["single", "loss"] == pytest.approx(0.3)
+    explicit = analysis.final_metrics_by_strategy(str(tmp_path), 1, {"ddp": ["ddp-job1"]}).set_index("strategy")
+    assert explicit.loc["ddp", "val_accuracy"] == pytest.approx(0.80)
+
+
+def test_communication_summary_excludes_first_iteration(tmp_path):
+    lg = CsvMetricLogger(str(tmp_path), "communicationtime-kk5nb4q5905j3c", 0, 0)
+    # first rows of that job as printed in ipynb/main.ipynb:541-545
+    for i, ms in enumerate([297.702393, 0.544768, 0.537600, 0.534528, 0.530432]):
+        lg.log_row("communication_time.csv", ["communicationtime-kk5nb4q5905j3c", i, ms])
+    lg.log_row("communication_sweep.csv", ["communicationtime-kk5nb4q5905j3c", "send_recv", 4096, 0.02, 0.01, 0.2, None, 2])
+    c = analysis.communication_summary(str(tmp_path)).iloc[0]
+    assert c["first_iteration"] == pytest.approx(297.702393)
+    assert c["elapsed_time"] == pytest.approx((0.544768 + 0.537600 + 0.534528 + 0.530432) / 4)
+    assert len(analysis.sweep_table(str(tmp_path))) == 1
+    analysis.main(["--log-dir", str(tmp_path), "--epoch", "1"])
+
+
+def test_notebook_is_valid_and_uses_the_module():
+    import json
+    nb = json.load(open(os.path.join(os.path.dirname(__file__), "..", "ipynb", "main.ipynb")))
+    src = "\n".join("".join(c["source"]) for c in nb["cells"] if c["cell_type"] == "code")
+    assert nb["nbformat"] == 4 and "analysis.epoch_time_by_job" in src and "communication_summary" in src
+    compile(src, "main.ipynb", "exec")
