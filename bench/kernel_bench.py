@@ -16,7 +16,11 @@ ap.add_argument("--batch", type=int, default=30)
 ap.add_argument("--only", default=None)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--bm", type=int, default=0)
+ap.add_argument("--sweep", action="store_true", help="time every conv_gemm tile config per case")
+ap.add_argument("--cfg", type=int, default=-1, help="explicit conv_gemm tile config id (csrc/conv_gemm.hip)")
 a = ap.parse_args()
+if a.cfg >= 0:
+    a.bm = 1000 + a.cfg
 ext = ops.require_ext()
 dev = torch.device("cuda", 0)
 B = a.batch
@@ -37,6 +41,7 @@ def timeit(fn, iters=a.iters):
 
 
 cases = []
+NCFG = 18
 
 
 def case(name, flops):
@@ -97,6 +102,17 @@ for (blk, H, Cl, Cf) in [("b1", 56, 160, 256), ("b2", 28, 320, 512), ("b3", 14, 
 
 for name, flops, fn in cases:
     if a.only and a.only != name:
+        continue
+    if a.sweep:
+        if "wgrad" in name:
+            continue
+        res = []
+        for cfg in [-1] + list(range(NCFG)):
+            a.bm = 0 if cfg < 0 else 1000 + cfg
+            res.append(timeit(fn, 10))
+        best = min(range(1, NCFG + 1), key=lambda i: res[i])
+        print(f"{name:20s} auto {res[0]:6.1f} | " + " ".join(f"{r:6.1f}" for r in res[1:]) +
+              f" | best cfg {best - 1} {res[best]:6.1f} us", flush=True)
         continue
     us = timeit(fn)
     print(f"{name:24s} {us:9.1f} us  {flops / us / 1e6:7.1f} TFLOP/s", flush=True)

@@ -46,6 +46,12 @@ ddl::RowSrc make_src(const at::Tensor& x0, const OptT& x1, const OptT& s0, const
     TORCH_CHECK(r.s0 != nullptr && r.s1 != nullptr, name, ": a second source needs s0, s1, s2");
   }
   r.relu = relu ? 1 : 0;
+  // extents for the buffer descriptors (32-bit offsets, hardware bounds check)
+  const int64_t b0 = ((rows - 1) * (int64_t)r.ld0 + ch) * 4;
+  const int64_t b1 = r.X1 ? ((rows - 1) * (int64_t)r.ld1 + ch) * 4 : 0;
+  TORCH_CHECK(b0 < (1LL << 31) && b1 < (1LL << 31), name, ": operand view must span < 2 GiB");
+  r.bytes0 = (unsigned)b0;
+  r.bytes1 = (unsigned)b1;
   return r;
 }
 
@@ -84,6 +90,21 @@ at::Tensor conv_gemm(const at::Tensor& x0, const OptT& x1, const OptT& s0, const
   TORCH_CHECK(stats_mode >= 0 && stats_mode <= 2, "stats_mode");
   if (stats_mode == 2) { TORCH_CHECK(p.aux, "stats_mode 2 needs aux"); }
   p.stats = (int)stats_mode;
+  // operation kind: the combinations DenseNet uses (conv_gemm.hip)
+  const bool two = x1.has_value();
+  if (!two && !b_kmajor && !ep_mask && !ep_accum && stats_mode != 2) p.kind = 0;
+  else if (!two && b_kmajor && !ep_mask && !ep_accum && stats_mode != 2) p.kind = 1;
+  else if (two && b_kmajor && ep_mask && !ep_accum && stats_mode != 1) p.kind = 2;
+  else if (two && b_kmajor && ep_mask && ep_accum && stats_mode != 1) p.kind = 3;
+  else TORCH_CHECK(false, "conv_gemm: unsupported operand / epilogue combination");
+  const int64_t cch = C / 32;
+  TORCH_CHECK(taps * cch <= 320, "conv_gemm: K too large for the sub-slab index arithmetic");
+  p.inv_cc = (int)((65536 + cch - 1) / cch);
+  const int64_t wb = b_kmajor ? ((C - 1) * (int64_t)p.ldb + taps * N) * 4 : ((N - 1) * (int64_t)p.ldb + taps * C) * 4;
+  const int64_t ob = ((M - 1) * (int64_t)p.ldo + N) * 4;
+  const int64_t xb = p.aux ? ((M - 1) * (int64_t)p.ldaux + N) * 4 : 0;
+  TORCH_CHECK(wb < (1LL << 31) && ob < (1LL << 31) && xb < (1LL << 31), "conv_gemm: views must span < 2 GiB");
+  p.wbytes = (unsigned)wb; p.obytes = (unsigned)ob; p.auxbytes = (unsigned)xb;
   at::Tensor stats;
   if (stats_mode) {
     const int G = ddl::conv_gemm_grid_x((int)M, (int)N, (int)force_bm);

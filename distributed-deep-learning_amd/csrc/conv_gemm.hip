@@ -40,10 +40,38 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-template <int BM, int BN, int WM, int WN, int KS, bool TWO, bool KMAJOR>
+// Buffer (SRD) addressing: 32-bit byte offsets against a wave-uniform descriptor with hardware bounds
+// checking - an out-of-range offset loads 0 and drops stores.  Every "is this row / tap / column
+// valid" decision becomes a select between the real offset and OOB, so the operand loads and the
+// epilogue are straight-line code (the branchy flat-address form spent ~10x more instructions on
+// addressing than on MFMA issue and serialised its loads behind vmcnt(0) waits).
+constexpr unsigned OOB = 0x80000000u;     // beyond any descriptor: views are < 2 GiB (checked on the host)
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bld4(rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ float bld1(rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ void bst1(rsrc_t r, unsigned off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 0);
+}
+
+// Operation kinds (what DenseNet needs; anything else is rejected on the host):
+//   0 FWD     one source, n-major weights, plain store            (+ column statistics v, v*v)
+//   1 TDGRAD  one source, k-major weights, plain store            (transition data gradient)
+//   2 DGRAD3  two sources, k-major, masked store                  (+ statistics g, g*aux)
+//   3 DGRAD1  two sources, k-major, masked accumulate into out    (+ statistics g, g*aux)
+template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF, int KIND>
 __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const ConvGemmParams p) {
+  constexpr bool TWO = KIND >= 2, KMAJOR = KIND >= 1, EPM = KIND >= 2, EPA = KIND == 3;
   constexpr int NT = 64 * WM * WN * KS;
   constexpr int TM = BM / (32 * WM);
   constexpr int TN = BN / (32 * WN);
@@ -55,12 +83,15 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
   constexpr int PA = (BM * Q) / NT;
   constexpr int PB = (BN * Q) / NT;
   constexpr int B_ELEMS = KMAJOR ? BKT * LDBK : BN * LDA;
+  constexpr int BQ4 = BN / 4;            // float4 per row of the K-major weight image
+  constexpr int KROWS = NT / BQ4;        // K rows covered per pass of the K-major weight load
   static_assert((BM * Q) % NT == 0 && (BN * Q) % NT == 0 && NT % Q == 0, "slab must divide over the workgroup");
+  static_assert(NT % BQ4 == 0, "k-major weight slab must divide over the workgroup");
   static_assert(TM >= 1 && TN >= 1, "bad wave layout");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                        // [2][BM][LDA]
-  float* Bs = smem + 2 * BM * LDA;         // [2][B_ELEMS]
+  float* As = smem;                        // [NBUF][BM][LDA]
+  float* Bs = smem + NBUF * BM * LDA;      // [NBUF][B_ELEMS]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int ks = wid / (WM * WN);
@@ -75,130 +106,135 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
     tile_x = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
-  const long m0 = (long)tile_x * BM;
+  const int m0 = tile_x * BM;
   const int n0 = blockIdx.y * BN;
   const int cchunks = p.C >> 5;            // 32-wide sub-slabs per tap (C % 32 == 0, checked on host)
   const int NS = p.taps * cchunks;         // sub-slabs in all
   const int KT = (NS + KS - 1) / KS;
-  const int HW = p.H * p.W;
+
+  const rsrc_t rA0 = make_rsrc(p.a.X0, p.a.bytes0);
+  const rsrc_t rA1 = make_rsrc(TWO ? p.a.X1 : p.a.X0, TWO ? p.a.bytes1 : p.a.bytes0);
+  const rsrc_t rW = make_rsrc(p.Wt, p.wbytes);
+  const bool affine = p.a.s0 != nullptr;
 
   // ---- per-thread bookkeeping -----------------------------------------------------------------
   const int aq = tid % Q;                  // this thread's float4 column inside a slab row
   const int a_sub = aq >> 3;               // which 32-wide sub-slab
   const int a_col = 4 * (aq & 7);          // channel offset inside it
   const int a_row0 = tid / Q;
-  long a_m[PA];
-  int a_y[PA], a_x[PA];
-  bool a_ok[PA];
+  unsigned a_off0[PA], a_off1[TWO ? PA : 1], a_bits[PA];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
-    const long m = m0 + a_row0 + i * RSTEP;
-    a_m[i] = m;
-    a_ok[i] = m < p.M;
-    a_y[i] = 0;
-    a_x[i] = 0;
-    if (p.taps > 1) {
-      const int rem = (int)(m % HW);
-      a_y[i] = rem / p.W;
-      a_x[i] = rem - a_y[i] * p.W;
+    const int m = m0 + a_row0 + i * RSTEP;
+    a_off0[i] = (unsigned)m * (unsigned)(p.a.ld0 * 4);
+    if (TWO) a_off1[i] = (unsigned)m * (unsigned)(p.a.ld1 * 4);
+    unsigned bits = 0;
+    if (m < p.M) {
+      bits = 1;
+      if (p.taps > 1) {       // bit t: tap t of this pixel lies inside the image (flip: offsets negated)
+        const int rem = m % (p.H * p.W);
+        const int y = rem / p.W, x = rem - y * p.W;
+        const unsigned up = y > 0, down = y < p.H - 1, left = x > 0, right = x < p.W - 1;
+        const unsigned yb = p.flip ? (down | 2u | (up << 2)) : (up | 2u | (down << 2));
+        const unsigned xb = p.flip ? (right | 2u | (left << 2)) : (left | 2u | (right << 2));
+        bits = ((yb & 1u) ? xb : 0u) | ((yb & 2u) ? (xb << 3) : 0u) | ((yb & 4u) ? (xb << 6) : 0u);
+      }
     }
+    a_bits[i] = bits;
   }
+  unsigned b_off[PB];                      // n-major weights: byte offset of this thread's rows
+  if (!KMAJOR) {
+#pragma unroll
+    for (int i = 0; i < PB; ++i) b_off[i] = (unsigned)(n0 + a_row0 + i * RSTEP) * (unsigned)(p.ldb * 4);
+  }
+  const int bk_row = tid / BQ4;            // k-major weights: K row / output-channel quad of this thread
+  const int bk_n = n0 + 4 * (tid - bk_row * BQ4);
 
-  f32x4 a_v0[PA], a_v1[PA];
-  f32x4 a_s0, a_s1, a_s2;
-  unsigned a_mask = 0;
-  f32x4 b_reg[PB];
+  // one slab in flight in registers (PF = 2: two of them)
+  struct Stage {
+    f32x4 a_v0[PA], a_v1[TWO ? PA : 1];
+    f32x4 a_s0, a_s1, a_s2;
+    unsigned a_mask;
+    f32x4 b_reg[PB];
+  };
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  auto load_slab = [&](int kt) {
+  // sub-slab index -> (tap, first channel); inv_cc = ceil(2^16 / cchunks), exact for idx <= 320
+  auto split = [&](int idx, int& tap, int& c0) {
+    tap = (int)(((unsigned)idx * (unsigned)p.inv_cc) >> 16);
+    c0 = (idx - tap * cchunks) * 32;
+  };
+  auto tap_pix = [&](int tap) {            // pixel offset of a 3x3 tap (rows of the NHWC tensor)
+    const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;
+    const int o = (ty - 1) * p.W + (tx - 1);
+    return p.flip ? -o : o;
+  };
+
+  auto load_slab = [&](int kt, Stage& S) {
+    const int idx = kt * KS + a_sub;
+    const bool sub_ok = idx < NS;
+    int tap, c0;
+    split(idx, tap, c0);
+    const int c = c0 + a_col;
     {   // ---- A: rows gathered with this thread's tap offset, raw values only ----
-      const int idx = kt * KS + a_sub;
-      const bool sub_ok = idx < NS;
-      const int tap = sub_ok ? idx / cchunks : 0;
-      const int c = (idx - tap * cchunks) * 32 + a_col;
-      int dy = 0, dx = 0;
-      if (p.taps > 1) {
-        dy = tap / 3 - 1;
-        dx = tap - (tap / 3) * 3 - 1;
-        if (p.flip) { dy = -dy; dx = -dx; }
+      const int pix = p.taps > 1 ? tap_pix(tap) : 0;
+      const unsigned d0 = (unsigned)((pix * p.a.ld0 + c) * 4);
+      const unsigned d1 = TWO ? (unsigned)((pix * p.a.ld1 + c) * 4) : 0u;
+      S.a_s0 = zero4; S.a_s1 = zero4; S.a_s2 = zero4;
+      if (affine) {                        // c < C always (even for idx >= NS the loads stay in range)
+        S.a_s0 = ld4(p.a.s0 + c);
+        S.a_s2 = ld4(p.a.s2 + c);
+        if (TWO) S.a_s1 = ld4(p.a.s1 + c);
       }
-      const long off = (long)dy * p.W + dx;
-      a_s0 = zero4; a_s1 = zero4; a_s2 = zero4;
-      if (sub_ok && p.a.s0 != nullptr) {
-        a_s0 = ld4(p.a.s0 + c);
-        a_s2 = ld4(p.a.s2 + c);
-        if (TWO) a_s1 = ld4(p.a.s1 + c);
-      }
-      a_mask = 0;
+      S.a_mask = 0;
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
-        bool ok = a_ok[i] && sub_ok;
-        if (p.taps > 1) {
-          const int yy = a_y[i] + dy, xx = a_x[i] + dx;
-          ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-        }
-        a_v0[i] = zero4;
-        if (TWO) a_v1[i] = zero4;
-        if (ok) {
-          a_mask |= 1u << i;
-          a_v0[i] = ld4(p.a.X0 + (a_m[i] + off) * p.a.ld0 + c);
-          if (TWO) a_v1[i] = ld4(p.a.X1 + (a_m[i] + off) * p.a.ld1 + c);
-        }
+        const bool ok = sub_ok && ((a_bits[i] >> tap) & 1u);
+        S.a_mask |= ok ? (1u << i) : 0u;
+        S.a_v0[i] = bld4(rA0, ok ? a_off0[i] + d0 : OOB);
+        if (TWO) S.a_v1[i] = bld4(rA1, ok ? a_off1[i] + d1 : OOB);
       }
     }
     // ---- B ----
+    if (!KMAJOR) {                         // same (tap, c) as A: both index the slab row by tid % Q
+      const unsigned dcol = (unsigned)((tap * p.C + c) * 4);
 #pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const int f = tid + i * NT;
-      f32x4 v = zero4;
-      if (!KMAJOR) {
-        const int n = n0 + f / Q;
-        const int bq = f % Q;
-        const int idx = kt * KS + (bq >> 3);
-        if (n < p.N && idx < NS) {
-          const int tap = idx / cchunks;
-          const int c = (idx - tap * cchunks) * 32 + 4 * (bq & 7);
-          v = ld4(p.Wt + (long)n * p.ldb + (long)tap * p.C + c);
-        }
-      } else {
-        const int kk = f / (BN / 4);
-        const int n = n0 + 4 * (f - kk * (BN / 4));
-        const int idx = kt * KS + (kk >> 5);
-        if (n < p.N && idx < NS) {
-          const int tap = idx / cchunks;
-          const int c = (idx - tap * cchunks) * 32 + (kk & 31);
-          v = ld4(p.Wt + (long)c * p.ldb + (long)tap * p.N + n);
-        }
+      for (int i = 0; i < PB; ++i) S.b_reg[i] = bld4(rW, sub_ok ? b_off[i] + dcol : OOB);
+    } else {
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int kk = bk_row + i * KROWS;
+        const int bidx = kt * KS + (KS == 1 ? 0 : (kk >> 5));
+        int btap, bc0;
+        split(bidx, btap, bc0);
+        const unsigned off = (unsigned)(((bc0 + (kk & 31)) * p.ldb + btap * p.N + bk_n) * 4);
+        S.b_reg[i] = bld4(rW, (bidx < NS && bk_n < p.N) ? off : OOB);
       }
-      b_reg[i] = v;
     }
   };
 
-  auto store_slab = [&](int buf) {
+  auto store_slab = [&](int buf, const Stage& S) {
     float* Ab = As + buf * BM * LDA;
     float* Bb = Bs + buf * B_ELEMS;
-    const bool affine = p.a.s0 != nullptr;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-      f32x4 v = a_v0[i];
+      f32x4 v = S.a_v0[i];
       if (affine) {          // deferred prologue: BN affine (+ second source) + ReLU, zero where invalid
-        v = a_s0 * v + a_s2;
-        if (TWO) v += a_s1 * a_v1[i];
+        v = S.a_s0 * v + S.a_s2;
+        if (TWO) v += S.a_s1 * S.a_v1[i];
         if (p.a.relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        if (!((a_mask >> i) & 1u)) v = zero4;
+        if (!((S.a_mask >> i) & 1u)) v = zero4;
       }
       *reinterpret_cast<f32x4*>(Ab + (a_row0 + i * RSTEP) * LDA + 4 * aq) = v;
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      const int f = tid + i * NT;
       if (!KMAJOR) {
-        *reinterpret_cast<f32x4*>(Bb + (f / Q) * LDA + 4 * (f % Q)) = b_reg[i];
+        *reinterpret_cast<f32x4*>(Bb + (a_row0 + i * RSTEP) * LDA + 4 * aq) = S.b_reg[i];
       } else {
-        const int kk = f / (BN / 4);
-        *reinterpret_cast<f32x4*>(Bb + kk * LDBK + 4 * (f - kk * (BN / 4))) = b_reg[i];
+        *reinterpret_cast<f32x4*>(Bb + (bk_row + i * KROWS) * LDBK + 4 * (tid - bk_row * BQ4)) = S.b_reg[i];
       }
     }
   };
@@ -243,16 +279,41 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
     }
   };
 
-  // ---- main loop: register-staged double buffer ---------------------------------------------
-  load_slab(0);
-  store_slab(0);
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < KT) load_slab(kt + 1);      // global loads fly under this slab's MFMAs
-    compute(buf);
-    if (kt + 1 < KT) store_slab(buf ^ 1);
+  // ---- main loop: register-staged; NBUF = 2: one barrier per slab, NBUF = 1: half the LDS
+  // (more workgroups per CU hide the extra barrier and every other latency) -------------------
+  if (PF == 1) {
+    Stage S;
+    load_slab(0, S);
+    store_slab(0, S);
     __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+      const int buf = NBUF == 2 ? (kt & 1) : 0;
+      if (kt + 1 < KT) load_slab(kt + 1, S);      // global loads fly under this slab's MFMAs
+      compute(buf);
+      if (NBUF == 1) __syncthreads();
+      if (kt + 1 < KT) store_slab(NBUF == 2 ? (buf ^ 1) : 0, S);
+      __syncthreads();
+    }
+  } else {
+    // prefetch distance 2 (NBUF == 2): slab kt in LDS, slab kt+1 in registers, slab kt+2 being loaded.
+    // For the latency-bound small-M layers (a handful of workgroups per CU at most) a slab's loads
+    // get two compute phases to land instead of one.
+    Stage S0, S1;
+    load_slab(0, S0);
+    if (KT > 1) load_slab(1, S1);
+    store_slab(0, S0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; kt += 2) {
+      if (kt + 2 < KT) load_slab(kt + 2, S0);
+      compute(0);
+      if (kt + 1 < KT) store_slab(1, S1);
+      __syncthreads();
+      if (kt + 1 >= KT) break;
+      if (kt + 3 < KT) load_slab(kt + 3, S1);
+      compute(1);
+      if (kt + 2 < KT) store_slab(0, S0);
+      __syncthreads();
+    }
   }
 
   // ---- combine the K-split partial accumulators ---------------------------------------------
@@ -283,44 +344,45 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
   }
 
   // ---- epilogue (wave group ks == 0 holds the result) -----------------------------------------
+  // Straight-line: rows >= M and columns >= N fall outside the descriptors (loads give 0, stores are
+  // dropped) and their accumulators are exactly 0 (zeroed operand rows / weight columns), so neither
+  // the stores nor the statistics need per-element predicates.
   float st1[TN], st2[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) { st1[j] = 0.f; st2[j] = 0.f; }
   if (ks == 0) {
+    const rsrc_t rO = make_rsrc(p.out, p.obytes);
+    const rsrc_t rX = make_rsrc(EPM ? p.aux : p.out, EPM ? p.auxbytes : p.obytes);
+    const unsigned ldo4 = (unsigned)(p.ldo * 4), ldx4 = (unsigned)(p.ldaux * 4);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + (wn * TN + j) * 32 + li;
       const bool colok = col < p.N;
       float e0v = 1.f, e1v = 0.f;
-      if (colok && p.e0 != nullptr) e0v = p.e0[col];
-      if (colok && p.e1 != nullptr) e1v = p.e1[col];
+      if (EPM || EPA) {
+        e0v = p.e0[colok ? col : 0];
+        if (EPM) e1v = p.e1[colok ? col : 0];
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        // batch every global read of the tile (mask operand, old dBuf value) ahead of the stores:
-        // interleaved load/store pairs would serialise 16 dependent L2 round trips per tile
+        const unsigned row0 = (unsigned)(m0 + (wm * TM + i) * 32 + 4 * lh);
+        const unsigned obase = colok ? (row0 * (unsigned)p.ldo + (unsigned)col) * 4u : OOB;
+        const unsigned xbase = colok ? (row0 * (unsigned)p.ldaux + (unsigned)col) * 4u : OOB;
         float axv[16], oldv[16];
-        const long rbase = m0 + (wm * TM + i) * 32 + 4 * lh;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const long row = rbase + (r & 3) + 8 * (r >> 2);
-          axv[r] = 0.f;
-          oldv[r] = 0.f;
-          if (colok && row < p.M) {
-            if (p.ep_mask) axv[r] = p.aux[row * p.ldaux + col];
-            if (p.ep_accum) oldv[r] = p.out[row * p.ldo + col];
-          }
+        for (int r = 0; r < 16; ++r) {     // every read of the tile (mask operand, old dBuf) ahead of the stores
+          const unsigned k = (unsigned)((r & 3) + 8 * (r >> 2));
+          axv[r] = EPM ? bld1(rX, xbase + k * ldx4) : 0.f;
+          oldv[r] = EPA ? bld1(rO, obase + k * ldo4) : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const long row = rbase + (r & 3) + 8 * (r >> 2);
-          if (colok && row < p.M) {
-            float v = acc[i][j][r];
-            const float ax = axv[r];
-            if (p.ep_mask) v = (fmaf(e0v, ax, e1v) > 0.f) ? v : 0.f;
-            if (p.stats == 1) { st1[j] += v; st2[j] += v * v; }
-            else if (p.stats == 2) { st1[j] += v; st2[j] += v * ax; }
-            p.out[row * p.ldo + col] = p.ep_accum ? fmaf(e0v, v, oldv[r]) : v;
-          }
+          const unsigned k = (unsigned)((r & 3) + 8 * (r >> 2));
+          float v = acc[i][j][r];
+          if (EPM) v = (fmaf(e0v, axv[r], e1v) > 0.f) ? v : 0.f;
+          if (EPM) { st1[j] += v; st2[j] += v * axv[r]; }
+          else { st1[j] += v; st2[j] += v * v; }
+          bst1(rO, obase + k * ldo4, EPA ? fmaf(e0v, v, oldv[r]) : v);
         }
       }
     }
@@ -352,64 +414,100 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
   }
 }
 
-template <int BM, int BN, int WM, int WN, int KS, bool TWO, bool KMAJOR>
+template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF, int KIND>
 void launch_inst(const ConvGemmParams& p, hipStream_t s) {
+  constexpr bool KMAJOR = KIND >= 1;
   constexpr int BKT = 32 * KS;
   constexpr size_t b_elems = KMAJOR ? (size_t)BKT * (BN + 4) : (size_t)BN * (BKT + 4);
-  constexpr size_t lds = (2 * (size_t)BM * (BKT + 4) + 2 * b_elems) * sizeof(float);
+  constexpr size_t stage = (NBUF * (size_t)BM * (BKT + 4) + NBUF * b_elems) * sizeof(float);
+  // the K-split combine and the statistics reduce reuse the staging area
+  constexpr size_t red = ((size_t)(KS - 1) * (BM / 32) * (BN / 32) * 16 * 64 + 2 * WM * BN) * sizeof(float);
+  constexpr size_t lds = stage > red ? stage : red;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, KS, TWO, KMAJOR>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, KS, NBUF, PF, KIND>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.N + BN - 1) / BN));
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, KS, TWO, KMAJOR>), grid, dim3(64 * WM * WN * KS), lds, s, p);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, KS, NBUF, PF, KIND>), grid, dim3(64 * WM * WN * KS), lds, s, p);
 }
 
-template <int BM, int BN, int WM, int WN, int KS>
+template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF = 1>
 void launch_cfg(const ConvGemmParams& p, hipStream_t s) {
-  const bool two = p.a.X1 != nullptr, km = p.b_kmajor != 0;
-  if (two && km) launch_inst<BM, BN, WM, WN, KS, true, true>(p, s);
-  else if (two) launch_inst<BM, BN, WM, WN, KS, true, false>(p, s);
-  else if (km) launch_inst<BM, BN, WM, WN, KS, false, true>(p, s);
-  else launch_inst<BM, BN, WM, WN, KS, false, false>(p, s);
+  static_assert(PF == 1 || NBUF == 2, "prefetch distance 2 needs both LDS buffers");
+  switch (p.kind) {
+    case 0: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 0>(p, s); break;
+    case 1: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 1>(p, s); break;
+    case 2: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 2>(p, s); break;
+    default: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 3>(p, s); break;
+  }
+}
+
+// Tile configurations (BM, BN, waves M x N, K split, LDS buffers).  `force` >= 1000 selects
+// config (force - 1000) explicitly (bench/kernel_bench.py --cfg); 32/64/128 force the row-tile
+// height of the default family; 0 = heuristic.
+struct TileCfg { int bm, bn; };
+constexpr int NUM_CFG = 18;
+const TileCfg kCfg[NUM_CFG] = {{128, 128}, {64, 128}, {32, 128}, {128, 32}, {64, 32}, {32, 32},
+                               {128, 128}, {64, 128}, {32, 128}, {128, 32}, {64, 32}, {32, 32},
+                               {128, 128}, {64, 128}, {32, 128}, {128, 32}, {64, 32}, {32, 32}};
+
+void launch_by_id(int id, const ConvGemmParams& p, hipStream_t s) {
+  switch (id) {
+    case 0: launch_cfg<128, 128, 2, 2, 1, 2>(p, s); break;
+    case 1: launch_cfg<64, 128, 2, 2, 1, 2>(p, s); break;
+    case 2: launch_cfg<32, 128, 1, 4, 2, 2>(p, s); break;
+    case 3: launch_cfg<128, 32, 4, 1, 1, 2>(p, s); break;
+    case 4: launch_cfg<64, 32, 2, 1, 2, 2>(p, s); break;
+    case 5: launch_cfg<32, 32, 1, 1, 4, 2>(p, s); break;
+    case 6: launch_cfg<128, 128, 2, 2, 1, 1>(p, s); break;
+    case 7: launch_cfg<64, 128, 2, 2, 1, 1>(p, s); break;
+    case 8: launch_cfg<32, 128, 1, 4, 2, 1>(p, s); break;
+    case 9: launch_cfg<128, 32, 4, 1, 1, 1>(p, s); break;
+    case 10: launch_cfg<64, 32, 2, 1, 2, 1>(p, s); break;
+    case 11: launch_cfg<32, 32, 1, 1, 4, 1>(p, s); break;
+    case 12: launch_cfg<128, 128, 2, 2, 1, 2, 2>(p, s); break;
+    case 13: launch_cfg<64, 128, 2, 2, 1, 2, 2>(p, s); break;
+    case 14: launch_cfg<32, 128, 1, 4, 2, 2, 2>(p, s); break;
+    case 15: launch_cfg<128, 32, 4, 1, 1, 2, 2>(p, s); break;
+    case 16: launch_cfg<64, 32, 2, 1, 2, 2, 2>(p, s); break;
+    default: launch_cfg<32, 32, 1, 1, 4, 2, 2>(p, s); break;
+  }
 }
 
 // Row-tile height.  Measured on MI355X (bench/kernel_bench.py, B=30 shapes): for the 128-column
 // configs 64-row tiles beat 128-row tiles up to ~1500 row tiles (finer granularity = smaller tail
 // when tiles are dealt over 512 resident workgroup slots); the 32-column 3x3 forward prefers 128.
-int pick_bm(int M, int N, int force_bm) {
-  if (force_bm) return force_bm;
+int pick_cfg(int M, int N, int force) {
+  if (force >= 1000 && force < 1000 + NUM_CFG) return force - 1000;
+  int bm = (force == 32 || force == 64 || force == 128) ? force : 0;
   if (N > 32) {
-    const long nt = (N + 127) / 128;
-    if ((long)((M + 63) / 64) * nt >= 8192) return 128;
-    if ((long)((M + 63) / 64) * nt >= 256) return 64;
-    return 32;
+    if (!bm) {
+      const long nt = (N + 127) / 128;
+      if ((long)((M + 63) / 64) * nt >= 8192) bm = 128;
+      else if ((long)((M + 63) / 64) * nt >= 256) bm = 64;
+      else bm = 32;
+    }
+    return bm == 128 ? 0 : bm == 64 ? 1 : 2;
   }
-  if ((M + 127) / 128 >= 384) return 128;
-  if ((M + 63) / 64 >= 256) return 64;
-  return 32;
+  if (!bm) {
+    if ((M + 127) / 128 >= 384) bm = 128;
+    else if ((M + 63) / 64 >= 256) bm = 64;
+    else bm = 32;
+  }
+  return bm == 128 ? 3 : bm == 64 ? 4 : 5;
 }
 
 }  // namespace
 
-int conv_gemm_grid_x(int M, int N, int force_bm) {
-  const int bm = pick_bm(M, N, force_bm);
+int conv_gemm_grid_x(int M, int N, int force) {
+  const int bm = kCfg[pick_cfg(M, N, force)].bm;
   return (M + bm - 1) / bm;
 }
 
-void launch_conv_gemm(const ConvGemmParams& p, int force_bm, hipStream_t s) {
-  const int bm = pick_bm(p.M, p.N, force_bm);
-  if (p.N > 32) {
-    if (bm == 128) launch_cfg<128, 128, 2, 2, 1>(p, s);
-    else if (bm == 64) launch_cfg<64, 128, 2, 2, 1>(p, s);
-    else launch_cfg<32, 128, 1, 4, 2>(p, s);
-  } else {
-    if (bm == 128) launch_cfg<128, 32, 4, 1, 1>(p, s);
-    else if (bm == 64) launch_cfg<64, 32, 2, 1, 2>(p, s);
-    else launch_cfg<32, 32, 1, 1, 4>(p, s);
-  }
+void launch_conv_gemm(const ConvGemmParams& p, int force, hipStream_t s) {
+  launch_by_id(pick_cfg(p.M, p.N, force), p, s);
 }
 
 }  // namespace ddl

@@ -20,6 +20,8 @@ struct RowSrc {
   int ld0;
   int ld1;
   int relu;
+  unsigned bytes0;    // extent of the X0 / X1 views in bytes (buffer-descriptor bounds, < 2 GiB)
+  unsigned bytes1;
 };
 
 // out[M x N] (op)= rows(A)[M x taps*C] * W
@@ -45,6 +47,10 @@ struct ConvGemmParams {
   const float* e1;
   int stats;          // 0 none; 1: per-column sum(v), sum(v*v); 2: sum(g), sum(g*aux)
   float* stats_out;   // [gridDim.x][2][N]
+  // derived on the host (conv_bindings.cpp: finish_params)
+  int kind;           // 0 FWD, 1 TDGRAD, 2 DGRAD3, 3 DGRAD1 (see conv_gemm.hip)
+  int inv_cc;         // ceil(2^16 / (C / 32)): sub-slab index -> (tap, channel chunk) without a division
+  unsigned wbytes, obytes, auxbytes;   // extents of weight / out / aux in bytes
 };
 
 // dW[N x taps*C] += dO^T[N x M] * rows(A)[M x taps*C]   (weight gradient; split over M, slab output)
