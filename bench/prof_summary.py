@@ -20,11 +20,10 @@ for r in sel:
     busy += d
     n = r["Kernel_Name"]
     g = (int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
-    m = re.search(r"conv_gemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\w+)>", n)
+    m = re.search(r"conv_gemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", n)
     if m:
-        n = "conv_gemm<%s,%s,ks%s,%s,%s>" % (m.group(1), m.group(2), m.group(5),
-                                            "2src" if m.group(6) in ("true", "1") else "1src",
-                                            "kmaj" if m.group(7) in ("true", "1") else "nmaj")
+        n = "conv_gemm<%s,%s,ks%s,nbuf%s,pf%s,%s>" % (m.group(1), m.group(2), m.group(5), m.group(6), m.group(7),
+                                                     ("fwd", "tdgrad", "dgrad3x3", "dgrad1x1")[int(m.group(8))])
     else:
         m = re.search(r"(wgrad\dx\d_kernel|slab_reduce_kernel|bn_prep_kernel|bn_bwd_prep_kernel|rows_op_kernel|"
                       r"adam_flat_kernel|ce_fwd_bwd_kernel|normalize_u8_kernel|bnrelu_gap_fwd_kernel|stem_\w+_kernel|"

@@ -476,25 +476,30 @@ void launch_by_id(int id, const ConvGemmParams& p, hipStream_t s) {
   }
 }
 
-// Row-tile height.  Measured on MI355X (bench/kernel_bench.py, B=30 shapes): for the 128-column
-// configs 64-row tiles beat 128-row tiles up to ~1500 row tiles (finer granularity = smaller tail
-// when tiles are dealt over 512 resident workgroup slots); the 32-column 3x3 forward prefers 128.
+// Heuristic from the measured sweep (bench/kernel_bench.py --sweep, B=30 shapes, MI355X):
+//  * few row tiles (block 4 at batch 30: M = 1470): 32-column tiles, so the output-channel axis
+//    supplies the workgroups that the pixel axis cannot (fwd 1x1: 20.5 -> 10.7 us);
+//  * 128-column family: 64-row tiles beat 128-row tiles up to ~1500 row tiles (smaller tail when
+//    tiles are dealt over the resident slots), single LDS buffer (4 workgroups / CU) >= double;
+//  * 32-column family (3x3 forward): 128 rows for the big maps, 32 rows x 4-way K split below.
 int pick_cfg(int M, int N, int force) {
   if (force >= 1000 && force < 1000 + NUM_CFG) return force - 1000;
   int bm = (force == 32 || force == 64 || force == 128) ? force : 0;
   if (N > 32) {
+    if (!bm && M <= 2048)
+      return ((long)((M + 63) / 64) * ((N + 31) / 32) >= 256) ? 4 : 5;
     if (!bm) {
       const long nt = (N + 127) / 128;
       if ((long)((M + 63) / 64) * nt >= 8192) bm = 128;
       else if ((long)((M + 63) / 64) * nt >= 256) bm = 64;
       else bm = 32;
     }
-    return bm == 128 ? 0 : bm == 64 ? 1 : 2;
+    return bm == 128 ? 0 : bm == 64 ? 7 : 2;
   }
   if (!bm) {
     if ((M + 127) / 128 >= 384) bm = 128;
-    else if ((M + 63) / 64 >= 256) bm = 64;
-    else bm = 32;
+    else if ((M + 63) / 64 >= 512) bm = 64;
+    else return (M + 63) / 64 >= 256 ? 11 : 5;
   }
   return bm == 128 ? 3 : bm == 64 ? 4 : 5;
 }

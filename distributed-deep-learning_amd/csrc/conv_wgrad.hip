@@ -28,27 +28,56 @@ namespace {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// Buffer (SRD) addressing, as in conv_gemm.hip: 32-bit byte offsets, hardware bounds check, an
+// invalid row / column selects the OOB offset (loads 0) - the staging loads are straight-line code.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr unsigned OOB = 0x80000000u;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bld4(rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+
 // Per-thread operand column state: a thread always stages the same channel quad, so the affine
 // vectors are fetched once; pixel data is fetched raw one step ahead and transformed only when it
 // is written to LDS (after the current step's MFMAs) - the loads' latency hides under the MFMAs.
 struct ColAffine {
   f32x4 s0, s1, s2;
-  bool affine, two, relu;
+  float lo;      // ReLU as max(v, lo): lo = 0 (ReLU) or -inf (none) - no branch in the staging path
 };
 
 __device__ __forceinline__ ColAffine col_affine(const RowSrc& a, int c, bool col_ok) {
   ColAffine k;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  k.s0 = z; k.s1 = z; k.s2 = z;
-  k.affine = a.s0 != nullptr;
-  k.two = a.X1 != nullptr;
-  k.relu = a.relu != 0;
-  if (k.affine && col_ok) {
-    k.s0 = ld4(a.s0 + c);
-    k.s2 = ld4(a.s2 + c);
-    if (k.two) k.s1 = ld4(a.s1 + c);
+  k.s0 = (f32x4){1.f, 1.f, 1.f, 1.f};      // identity when the source has no affine
+  k.s1 = z; k.s2 = z;
+  k.lo = a.relu != 0 ? 0.f : -__builtin_inff();
+  if (a.s0 != nullptr) {
+    const int cc = col_ok ? c : 0;
+    k.s0 = ld4(a.s0 + cc);
+    k.s2 = ld4(a.s2 + cc);
+    if (a.X1 != nullptr) k.s1 = ld4(a.s1 + cc);
   }
   return k;
+}
+
+// the two descriptors + row strides (bytes) of a row source
+struct SrcDesc {
+  rsrc_t r0, r1;
+  unsigned ld0, ld1;
+  bool two;
+};
+
+__device__ __forceinline__ SrcDesc src_desc(const RowSrc& a) {
+  SrcDesc d;
+  d.two = a.X1 != nullptr;
+  d.r0 = make_rsrc(a.X0, a.bytes0);
+  d.r1 = make_rsrc(d.two ? a.X1 : a.X0, d.two ? a.bytes1 : a.bytes0);
+  d.ld0 = (unsigned)(a.ld0 * 4);
+  d.ld1 = (unsigned)(a.ld1 * 4);
+  return d;
 }
 
 struct RawPix {
@@ -56,28 +85,24 @@ struct RawPix {
   bool ok;
 };
 
-__device__ __forceinline__ RawPix pix_fetch(const RowSrc& a, long row, int c, bool valid) {
+// TWO is a compile-time property of the call site (a run-time branch between the two loads would
+// make hipcc wait for the first before issuing the second)
+template <bool TWO>
+__device__ __forceinline__ RawPix pix_fetch(const SrcDesc& d, int row, int c, bool valid) {
   RawPix r;
-  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  r.v0 = z; r.v1 = z; r.ok = valid;
-  if (valid) {
-    r.v0 = ld4(a.X0 + row * a.ld0 + c);
-    if (a.X1 != nullptr) r.v1 = ld4(a.X1 + row * a.ld1 + c);
-  }
+  r.ok = valid;
+  r.v0 = bld4(d.r0, valid ? (unsigned)row * d.ld0 + (unsigned)(c * 4) : OOB);
+  r.v1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (TWO) r.v1 = bld4(d.r1, valid ? (unsigned)row * d.ld1 + (unsigned)(c * 4) : OOB);
   return r;
 }
 
+template <bool TWO>
 __device__ __forceinline__ f32x4 pix_apply(const RawPix& r, const ColAffine& k) {
-  f32x4 v = r.v0;
-  if (k.affine) {
-    v = k.s0 * v + k.s2;
-    if (k.two) v += k.s1 * r.v1;
-    if (k.relu) {
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-    }
-    if (!r.ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-  return v;
+  f32x4 v = k.s0 * r.v0 + k.s2;
+  if (TWO) v += k.s1 * r.v1;
+  v.x = fmaxf(v.x, k.lo); v.y = fmaxf(v.y, k.lo); v.z = fmaxf(v.z, k.lo); v.w = fmaxf(v.w, k.lo);
+  return r.ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
 constexpr int RK = 32;   // pixels per slab step
@@ -86,6 +111,7 @@ constexpr int RK = 32;   // pixels per slab step
 // 1x1: output tile 128 (n) x 128 (c) per workgroup, 2x2 waves of 64x64.
 // grid = (c tiles, n tiles, S)
 // ---------------------------------------------------------------------------------------------
+template <bool DTWO>
 __global__ void __launch_bounds__(256) wgrad1x1_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ds = smem;                     // [2][RK][128]
@@ -94,31 +120,32 @@ __global__ void __launch_bounds__(256) wgrad1x1_kernel(const WgradParams p) {
   const int wm = wid >> 1, wn = wid & 1;
   const int li = lane & 31, lh = lane >> 5;
   const int c0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
-  const long mb = (long)blockIdx.z * p.rows_per_wg;
-  long me = mb + p.rows_per_wg;
+  const int mb = blockIdx.z * p.rows_per_wg;
+  int me = mb + p.rows_per_wg;
   if (me > p.M) me = p.M;
-  const int steps = (int)((me - mb + RK - 1) / RK);
+  const int steps = (me - mb + RK - 1) / RK;
+  const SrcDesc dd = src_desc(p.d), da = src_desc(p.a);
 
   const int q = 4 * (tid & 31);          // this thread's channel quad in both tiles (f & 31 == tid & 31)
   const ColAffine kd = col_affine(p.d, n0 + q, n0 + q < p.N);
   const ColAffine ka = col_affine(p.a, c0 + q, c0 + q < p.C);
   RawPix d_raw[4], a_raw[4];
   auto load_step = [&](int st) {
-    const long mrow = mb + (long)st * RK;
+    const int mrow = mb + st * RK;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int f = tid + i * 256;
-      const long m = mrow + (f >> 5);
-      d_raw[i] = pix_fetch(p.d, m, n0 + q, m < me && n0 + q < p.N);
-      a_raw[i] = pix_fetch(p.a, m, c0 + q, m < me && c0 + q < p.C);
+      const int m = mrow + (f >> 5);
+      d_raw[i] = pix_fetch<DTWO>(dd, m, n0 + q, m < me && n0 + q < p.N);
+      a_raw[i] = pix_fetch<false>(da, m, c0 + q, m < me && c0 + q < p.C);
     }
   };
   auto store_step = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int f = tid + i * 256;
-      *reinterpret_cast<f32x4*>(Ds + buf * RK * 128 + (f >> 5) * 128 + q) = pix_apply(d_raw[i], kd);
-      *reinterpret_cast<f32x4*>(As + buf * RK * 128 + (f >> 5) * 128 + q) = pix_apply(a_raw[i], ka);
+      *reinterpret_cast<f32x4*>(Ds + buf * RK * 128 + (f >> 5) * 128 + q) = pix_apply<DTWO>(d_raw[i], kd);
+      *reinterpret_cast<f32x4*>(As + buf * RK * 128 + (f >> 5) * 128 + q) = pix_apply<false>(a_raw[i], ka);
     }
   };
 
@@ -140,15 +167,27 @@ __global__ void __launch_bounds__(256) wgrad1x1_kernel(const WgradParams p) {
     if (st + 1 < steps) load_step(st + 1);
     const float* Db = Ds + buf * RK * 128 + wm * 64 + li;
     const float* Ab = As + buf * RK * 128 + wn * 64 + li;
+    // all 16 k-pairs' operands are read up front (64 VGPRs): the MFMAs then issue back to back
+    float d0[RK / 2], d1[RK / 2], a0[RK / 2], a1[RK / 2];
 #pragma unroll
     for (int s = 0; s < RK / 2; ++s) {
       const int r = 2 * s + lh;
-      const float d0 = Db[r * 128], d1 = Db[r * 128 + 32];
-      const float a0 = Ab[r * 128], a1 = Ab[r * 128 + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, a0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, a1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, a0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, a1, acc[1][1], 0, 0, 0);
+      d0[s] = Db[r * 128]; d1[s] = Db[r * 128 + 32];
+      a0[s] = Ab[r * 128]; a1[s] = Ab[r * 128 + 32];
+    }
+    // C grows by 32 per dense layer: the last channel tile is often mostly empty - skip its
+    // 32-column sub-tiles that lie beyond C (wave-uniform)
+    const bool c_lo = c0 + wn * 64 < p.C, c_hi = c0 + wn * 64 + 32 < p.C;
+#pragma unroll
+    for (int s = 0; s < RK / 2; ++s) {
+      if (c_lo) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d0[s], a0[s], acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1[s], a0[s], acc[1][0], 0, 0, 0);
+      }
+      if (c_hi) {
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d0[s], a1[s], acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1[s], a1[s], acc[1][1], 0, 0, 0);
+      }
     }
     if (st + 1 < steps) store_step(buf ^ 1);
     __syncthreads();
@@ -172,6 +211,7 @@ __global__ void __launch_bounds__(256) wgrad1x1_kernel(const WgradParams p) {
 // 3x3 (stride 1, pad 1), N = 32 output channels, C = 128 input channels per workgroup column
 // tile.  grid = (S, 3 (dy), C/128).  Wave w owns channels [32w, 32w+32) for the three dx taps.
 // ---------------------------------------------------------------------------------------------
+template <bool DTWO>
 __global__ void __launch_bounds__(256) wgrad3x3_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int AR = RK + 2;                       // activation rows staged per step (dx halo)
@@ -183,34 +223,35 @@ __global__ void __launch_bounds__(256) wgrad3x3_kernel(const WgradParams p) {
   const int dy = (int)blockIdx.y - 1;
   const int cbase = blockIdx.z * 128;
   const int HW = p.H * p.W;
-  const long mb = (long)blockIdx.x * p.rows_per_wg;
-  long me = mb + p.rows_per_wg;
+  const int mb = blockIdx.x * p.rows_per_wg;
+  int me = mb + p.rows_per_wg;
   if (me > p.M) me = p.M;
-  const int steps = (int)((me - mb + RK - 1) / RK);
+  const int steps = (me - mb + RK - 1) / RK;
+  const SrcDesc dd = src_desc(p.d), da = src_desc(p.a);
 
   const ColAffine kd = col_affine(p.d, 4 * (tid & 7), true);
   const ColAffine ka = col_affine(p.a, cbase + 4 * (tid & 31), cbase + 4 * (tid & 31) < p.C);
   RawPix d_raw, a_raw[5];
   int fl_reg = 0;
   auto load_step = [&](int st) {
-    const long mrow = mb + (long)st * RK;
+    const int mrow = mb + st * RK;
     {   // dO tile: 32 rows x 32 channels = 256 float4
-      const long m = mrow + (tid >> 3);
-      d_raw = pix_fetch(p.d, m, 4 * (tid & 7), m < me);
+      const int m = mrow + (tid >> 3);
+      d_raw = pix_fetch<DTWO>(dd, m, 4 * (tid & 7), m < me);
     }
 #pragma unroll
     for (int i = 0; i < 5; ++i) {   // activation rows mrow-1+dy*W ... (+AR), 128 channels
       const int f = tid + i * 256;
       const int r = f >> 5;
-      const long ms = mrow - 1 + (long)dy * p.W + r;
-      a_raw[i] = pix_fetch(p.a, ms, cbase + 4 * (f & 31),
+      const int ms = mrow - 1 + dy * p.W + r;
+      a_raw[i] = pix_fetch<false>(da, ms, cbase + 4 * (f & 31),
                            r < AR && ms >= 0 && ms < p.M && cbase + 4 * (f & 31) < p.C);
     }
     if (tid < RK) {
-      const long m = mrow + tid;
+      const int m = mrow + tid;
       int fl = 0;
       if (m < me) {
-        const int rem = (int)(m % HW);
+        const int rem = m % HW;
         const int y = rem / p.W, x = rem - y * p.W;
         if (y + dy >= 0 && y + dy < p.H) {
           if (x - 1 >= 0) fl |= 1;
@@ -222,12 +263,12 @@ __global__ void __launch_bounds__(256) wgrad3x3_kernel(const WgradParams p) {
     }
   };
   auto store_step = [&](int buf) {
-    *reinterpret_cast<f32x4*>(Ds + buf * RK * 32 + (tid >> 3) * 32 + 4 * (tid & 7)) = pix_apply(d_raw, kd);
+    *reinterpret_cast<f32x4*>(Ds + buf * RK * 32 + (tid >> 3) * 32 + 4 * (tid & 7)) = pix_apply<DTWO>(d_raw, kd);
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const int f = tid + i * 256;
       if ((f >> 5) < AR)
-        *reinterpret_cast<f32x4*>(As + buf * AR * 128 + (f >> 5) * 128 + 4 * (f & 31)) = pix_apply(a_raw[i], ka);
+        *reinterpret_cast<f32x4*>(As + buf * AR * 128 + (f >> 5) * 128 + 4 * (f & 31)) = pix_apply<false>(a_raw[i], ka);
     }
     if (tid < RK) Fl[buf * RK + tid] = fl_reg;
   };
@@ -324,18 +365,25 @@ void launch_wgrad(const WgradParams& p, float* dW, hipStream_t s) {
   const size_t lds1 = (size_t)4 * RK * 128 * sizeof(float);
   const size_t lds3 = (size_t)(2 * RK * 32 + 2 * (RK + 2) * 128 + 2 * RK) * sizeof(float);
   if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x1_kernel),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x1_kernel<false>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x1_kernel<true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<true>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
     attr = true;
   }
+  const bool two = p.d.X1 != nullptr;
   if (p.taps == 1) {
     dim3 grid((p.C + 127) / 128, (p.N + 127) / 128, p.S);
-    hipLaunchKernelGGL(wgrad1x1_kernel, grid, dim3(256), lds1, s, p);
+    if (two) hipLaunchKernelGGL(wgrad1x1_kernel<true>, grid, dim3(256), lds1, s, p);
+    else hipLaunchKernelGGL(wgrad1x1_kernel<false>, grid, dim3(256), lds1, s, p);
   } else {
     dim3 grid(p.S, 3, (p.C + 127) / 128);
-    hipLaunchKernelGGL(wgrad3x3_kernel, grid, dim3(256), lds3, s, p);
+    if (two) hipLaunchKernelGGL(wgrad3x3_kernel<true>, grid, dim3(256), lds3, s, p);
+    else hipLaunchKernelGGL(wgrad3x3_kernel<false>, grid, dim3(256), lds3, s, p);
   }
   const long total4 = (long)p.N * p.taps * p.C / 4;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total4 + 15) / 16)), dim3(256), 0, s,
