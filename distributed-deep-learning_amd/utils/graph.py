@@ -77,7 +77,8 @@ class GraphedTrainStep:
         c.graph = torch.cuda.CUDAGraph()
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
-        with torch.cuda.graph(c.graph, pool=self._pool):
+        # thread-local capture mode: the RCCL watchdog thread polls events while we capture
+        with torch.cuda.graph(c.graph, pool=self._pool, capture_error_mode="thread_local"):
             c.loss, c.out, c.preds = self._fwd_bwd(c.x, c.y)
             if not self.distributed:
                 self.optimizer.step()
