@@ -57,6 +57,7 @@ class TrainConfig:
     grad_sync: str = "rs_ag"            # rs_ag (reduce-scatter + all-gather) | allreduce
     zero1: bool = False                 # shard the Adam step over the dp group (RS grads, AG params)
     sync_buffers: str = "forward"       # forward (DDP parity) | epoch | off
+    grad_phases: str = "denseblock3,denseblock2"   # units that open a new backward graph phase (DP overlap)
     # ---- pipeline parallel (reference: pp.py:378-386) ------------------------
     num_microbatches: int = 5
     schedule: str = "1f1b"              # 1f1b | gpipe

@@ -409,7 +409,7 @@ class NativeDenseNetStage(nn.Module):
 
     def __init__(self, units: Sequence[str] = UNIT_NAMES, num_classes: int = 5, device="cuda",
                  dtype: str = "fp32", bucket_mb: float = 8.0, dp_world: int = 1,
-                 wgrad_min_rows: int = 64) -> None:
+                 wgrad_min_rows: int = 64, grad_phases: Sequence[str] = ()) -> None:
         super().__init__()
         if dtype != "fp32":
             raise NotImplementedError("the native engine is fp32 (reference parity); bf16 MFMA mode is not built yet")
@@ -429,9 +429,20 @@ class NativeDenseNetStage(nn.Module):
             if isinstance(mod, nn.Conv2d) and name != "features.conv0":
                 mod.weight = nn.Parameter(self._to_native(mod.weight.data))
         self.to(device)
-        self.arena = FlatArena(reverse_named_parameters(self), device=device,
+        # backward phases: ``grad_phases`` names the units that open a new phase (forward order).
+        # Each phase is one contiguous run of units; gradient buckets are cut at phase boundaries.
+        self.phase_starts: List[int] = sorted({self.units.index(u) for u in grad_phases if u in self.units} - {0})
+        rev = reverse_named_parameters(self)
+        breaks = []
+        for start in self.phase_starts:      # first parameter (in backward order) of the unit before the cut
+            prior = set(self.units[:start])
+            for n, _ in rev:
+                if self.unit_of_param(n) in prior:
+                    breaks.append(n)
+                    break
+        self.arena = FlatArena(rev, device=device,
                                segment_numel=max(int(bucket_mb * 2 ** 20 / 4), 1),
-                               segment_multiple=max(dp_world, 1) * 64)
+                               segment_multiple=max(dp_world, 1) * 64, break_before=breaks)
         self.flat_buffers = FlatBuffers(self, device)
         self.param_index: Dict[str, int] = {n: i for i, n in enumerate(self.arena.names)}
         self._buffers_by_name = dict(self.named_buffers())
@@ -452,6 +463,14 @@ class NativeDenseNetStage(nn.Module):
                 self.unit_objs.append(HeadUnit(self))
         for u in self.unit_objs:
             u.bind()
+
+    @staticmethod
+    def unit_of_param(fqn: str) -> str:
+        """Unit that owns a parameter (torchvision FQN)."""
+        if fqn.startswith("classifier.") or fqn.startswith("features.norm5."):
+            return "head"
+        part = fqn.split(".")[1]
+        return "stem" if part in ("conv0", "norm0") else part
 
     # ---- layout conversion (checkpoint boundary) -------------------------------------------
     @staticmethod
@@ -514,6 +533,32 @@ class NativeDenseNetStage(nn.Module):
     @property
     def is_last(self) -> bool:
         return self.units[-1] == "head"
+
+    def forward_phased(self, x: torch.Tensor):
+        """Forward with the autograd graph cut at the phase boundaries: returns ``(out, cuts)`` where
+        ``cuts[i] = (y, y_leaf)`` - ``y`` is the boundary activation as produced, ``y_leaf`` the detached
+        leaf the following units consumed.  ``out.backward()`` stops at the last cut; then
+        ``y.backward(y_leaf.grad)`` for the cuts in reverse order runs the earlier phases - each call
+        can be its own hipGraph, with that phase's gradient buckets handed to RCCL in between."""
+        stats, cuts = None, []
+        for i, u in enumerate(self.unit_objs):
+            if i in self.phase_starts:
+                leaf = x.detach().requires_grad_(True)
+                cuts.append((x, leaf))
+                x = leaf
+            x, stats = u(x, stats)
+        if self.training:
+            self._bump_counters()
+        return x, cuts
+
+    def phase_param_names(self) -> List[List[str]]:
+        """Parameter names per backward phase, in execution order (last units first)."""
+        bounds = [0] + self.phase_starts + [len(self.units)]
+        out = []
+        for a, b in reversed(list(zip(bounds[:-1], bounds[1:]))):
+            units = set(self.units[a:b])
+            out.append([n for n in self.arena.names if self.unit_of_param(n) in units])
+        return out
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         stats = None

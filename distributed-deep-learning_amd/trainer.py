@@ -153,7 +153,11 @@ class DDPStrategy(Strategy):
 
     @staticmethod
     def _native_kw(cfg, world):
-        return dict(bucket_mb=cfg.bucket_mb, dp_world=world) if cfg.impl != "torch" else {}
+        if cfg.impl == "torch":
+            return {}
+        # phased backward graphs (utils/graph.py) only matter when there is something to overlap with
+        phases = tuple(u for u in cfg.grad_phases.split(",") if u) if (world > 1 and cfg.hip_graph) else ()
+        return dict(bucket_mb=cfg.bucket_mb, dp_world=world, grad_phases=phases)
 
     def train_step(self, x, y, batch_size):
         # eager form: buffer broadcast -> forward -> backward (bucket collectives launched by the

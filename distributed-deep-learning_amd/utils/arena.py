@@ -16,7 +16,9 @@ Layout: parameters in the order given (callers pass *reverse registration order*
 that the first segment holds the last layers, whose gradients are ready first), each
 parameter start aligned to ``align`` elements, cut into segments of about
 ``segment_numel`` elements, each segment padded to a multiple of ``segment_multiple``
-(= dp_world * align, so a segment splits evenly for reduce-scatter).
+(= dp_world * align, so a segment splits evenly for reduce-scatter).  ``break_before`` names
+parameters that must open a new segment (the native engine aligns segments with the phases of
+its phased backward graphs, so a phase's buckets are complete when its graph has run).
 """
 from __future__ import annotations
 
@@ -49,7 +51,7 @@ def _round_up(x: int, m: int) -> int:
 class FlatArena:
     def __init__(self, named_params: Sequence[Tuple[str, torch.nn.Parameter]], device=None,
                  dtype=torch.float32, align: int = 64, segment_numel: int = 0,
-                 segment_multiple: int = 64) -> None:
+                 segment_multiple: int = 64, break_before: Iterable[str] = ()) -> None:
         named_params = [(n, p) for n, p in named_params]
         if not named_params:
             raise ValueError("FlatArena needs at least one parameter")
@@ -57,13 +59,14 @@ class FlatArena:
         self.dtype = dtype
         self.align = align
         segment_multiple = _round_up(max(segment_multiple, align), align)
+        break_before = set(break_before)      # parameter names that must start a new segment
         self.slots: List[Slot] = []
         self.segments: List[Segment] = []
         off = 0
         seg_start, seg_slots = 0, []
         for i, (name, p) in enumerate(named_params):
             n = p.numel()
-            if segment_numel and seg_slots and (off + n - seg_start) > segment_numel:
+            if seg_slots and ((segment_numel and (off + n - seg_start) > segment_numel) or name in break_before):
                 end = _round_up(off, segment_multiple)
                 self.segments.append(Segment(seg_start, end, seg_slots))
                 off, seg_start, seg_slots = end, end, []
