@@ -31,7 +31,7 @@ for case, c in cases.items():
     print(f"   waves/dispatch {c['SQ_WAVES'] / n:.0f}   MFMA insts/wave {mfma / max(c['SQ_WAVES'], 1):.0f}   "
           f"VALU insts per MFMA {c['SQ_INSTS_VALU'] / max(mfma, 1):.2f}   SALU per MFMA {c['SQ_INSTS_SALU'] / max(mfma, 1):.2f}   "
           f"LDS insts per MFMA {c['SQ_INSTS_LDS'] / max(mfma, 1):.2f}   VMEM reads per MFMA {c['SQ_INSTS_VMEM_RD'] / max(mfma, 1):.3f}")
-    util = mfma * 64 / max(us * 1e-6 * 2.4e9 * 1024, 1)
+    util = (mfma / n) * 64 / max(us * 1e-6 * 2.4e9 * 1024, 1)
     print(f"   MFMA pipe utilisation {100 * util:.0f} %  (v_mfma_f32_32x32x2_f32 = 64 cycles per SIMD; 1024 SIMDs at 2.4 GHz)")
     print(f"   MFMA-busy / wave-cycles {c['SQ_VALU_MFMA_BUSY_CYCLES'] / max(c['SQ_WAVE_CYCLES'], 1):.3f}   "
           f"wait-any / wave-cycles {c['SQ_WAIT_ANY'] / max(c['SQ_WAVE_CYCLES'], 1):.3f}   "
