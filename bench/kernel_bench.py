@@ -16,6 +16,7 @@ ap.add_argument("--batch", type=int, default=30)
 ap.add_argument("--only", default=None)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--bm", type=int, default=0)
+ap.add_argument("--min-rows", type=int, default=64, help="wgrad: minimum pixel rows per workgroup")
 ap.add_argument("--sweep", action="store_true", help="time every conv_gemm tile config per case")
 ap.add_argument("--cfg", type=int, default=-1, help="explicit conv_gemm tile config id (csrc/conv_gemm.hip)")
 a = ap.parse_args()
@@ -92,12 +93,12 @@ for (blk, H, Cl, Cf) in [("b1", 56, 160, 256), ("b2", 28, 320, 512), ("b3", 14, 
     cases.append((f"{blk}_dgrad1x1_N{Cl}", 2.0 * M * Cl * 128, f4))
 
     def f5(M=M, g2=g2, h=h, k=k, buf=buf, Cl=Cl, sc=sc, sh=sh, gw1=gw1, H=H):
-        ext.conv_wgrad(g2, h, k[0], k[1], k[2], buf[:, :Cl], sc, sh, True, M, H, H, 1, gw1, 64)
+        ext.conv_wgrad(g2, h, k[0], k[1], k[2], buf[:, :Cl], sc, sh, True, M, H, H, 1, gw1, a.min_rows)
     cases.append((f"{blk}_wgrad1x1_C{Cl}", 2.0 * M * Cl * 128, f5))
 
     def f6(M=M, dbuf=dbuf, buf=buf, Cl=Cl, ones=ones, sc=sc, sh=sh, h=h, gw2=gw2, H=H):
         ext.conv_wgrad(dbuf[:, Cl:Cl + 32], buf[:, Cl:Cl + 32], ones[:32], sc[:32], sh[:32], h, sc, sh, True, M, H, H,
-                       9, gw2, 64)
+                       9, gw2, a.min_rows)
     cases.append((f"{blk}_wgrad3x3", 2.0 * M * 1152 * 32, f6))
 
 for name, flops, fn in cases:

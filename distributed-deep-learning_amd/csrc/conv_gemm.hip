@@ -60,8 +60,8 @@ __device__ __forceinline__ f32x4 bld4(rsrc_t r, unsigned off) {
 __device__ __forceinline__ float bld1(rsrc_t r, unsigned off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
 }
-__device__ __forceinline__ void bst1(rsrc_t r, unsigned off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 0);
+__device__ __forceinline__ void bst4(rsrc_t r, unsigned off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)off, 0, 0);
 }
 
 // Operation kinds (what DenseNet needs; anything else is rejected on the host):
@@ -344,61 +344,74 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
   }
 
   // ---- epilogue (wave group ks == 0 holds the result) -----------------------------------------
-  // Straight-line: rows >= M and columns >= N fall outside the descriptors (loads give 0, stores are
-  // dropped) and their accumulators are exactly 0 (zeroed operand rows / weight columns), so neither
-  // the stores nor the statistics need per-element predicates.
-  float st1[TN], st2[TN];
+  // The MFMA C/D layout gives a lane 16 values of ONE column (rows strided by the row pitch): stored
+  // as is, a 32x32 tile costs 16 scalar stores (+ 32 scalar loads for the masked / accumulating
+  // kinds).  Each wave instead transposes its tile through LDS (the staging area is free now) so that
+  // a lane owns 4 consecutive columns of 4 rows: 4 dwordx4 loads / stores per tile and operand.
+  // Rows >= M and columns >= N fall outside the descriptors (loads give 0, stores are dropped) and
+  // their accumulators are exactly 0 (zeroed operand rows / weight columns): no per-element predicates.
+  constexpr int TLD = 36;                  // transposition image row stride (floats)
+  f32x4 st1[TN], st2[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) { st1[j] = 0.f; st2[j] = 0.f; }
+  for (int j = 0; j < TN; ++j) { st1[j] = zero4; st2[j] = zero4; }
+  const int erow = lane >> 3, ecq = lane & 7;      // epilogue role: row (+8p) and column quad of the tile
   if (ks == 0) {
     const rsrc_t rO = make_rsrc(p.out, p.obytes);
     const rsrc_t rX = make_rsrc(EPM ? p.aux : p.out, EPM ? p.auxbytes : p.obytes);
-    const unsigned ldo4 = (unsigned)(p.ldo * 4), ldx4 = (unsigned)(p.ldaux * 4);
+    float* T = smem + wmn * (32 * TLD);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int col = n0 + (wn * TN + j) * 32 + li;
-      const bool colok = col < p.N;
-      float e0v = 1.f, e1v = 0.f;
+      const int col = n0 + (wn * TN + j) * 32 + 4 * ecq;
+      const bool colok = col < p.N;        // N % 4 == 0: a column quad is valid or invalid as a whole
+      f32x4 e0v = {1.f, 1.f, 1.f, 1.f}, e1v = zero4;
       if (EPM || EPA) {
-        e0v = p.e0[colok ? col : 0];
-        if (EPM) e1v = p.e1[colok ? col : 0];
+        e0v = ld4(p.e0 + (colok ? col : 0));
+        if (EPM) e1v = ld4(p.e1 + (colok ? col : 0));
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const unsigned row0 = (unsigned)(m0 + (wm * TM + i) * 32 + 4 * lh);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lh) * TLD + li] = acc[i][j][r];
+        const unsigned row0 = (unsigned)(m0 + (wm * TM + i) * 32 + erow);
         const unsigned obase = colok ? (row0 * (unsigned)p.ldo + (unsigned)col) * 4u : OOB;
         const unsigned xbase = colok ? (row0 * (unsigned)p.ldaux + (unsigned)col) * 4u : OOB;
-        float axv[16], oldv[16];
+        f32x4 axv[4], oldv[4], v[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {     // every read of the tile (mask operand, old dBuf) ahead of the stores
-          const unsigned k = (unsigned)((r & 3) + 8 * (r >> 2));
-          axv[r] = EPM ? bld1(rX, xbase + k * ldx4) : 0.f;
-          oldv[r] = EPA ? bld1(rO, obase + k * ldo4) : 0.f;
+        for (int q = 0; q < 4; ++q) {      // every read of the tile (mask operand, old dBuf) ahead of the stores
+          axv[q] = EPM ? bld4(rX, xbase + (unsigned)(8 * q * p.ldaux * 4)) : zero4;
+          oldv[q] = EPA ? bld4(rO, obase + (unsigned)(8 * q * p.ldo * 4)) : zero4;
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const unsigned k = (unsigned)((r & 3) + 8 * (r >> 2));
-          float v = acc[i][j][r];
-          if (EPM) v = (fmaf(e0v, axv[r], e1v) > 0.f) ? v : 0.f;
-          if (EPM) { st1[j] += v; st2[j] += v * axv[r]; }
-          else { st1[j] += v; st2[j] += v * v; }
-          bst1(rO, obase + k * ldo4, EPA ? fmaf(e0v, v, oldv[r]) : v);
+        for (int q = 0; q < 4; ++q) v[q] = ld4(T + (erow + 8 * q) * TLD + 4 * ecq);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 g = v[q];
+          if (EPM) {
+            const f32x4 z = e0v * axv[q] + e1v;
+            g.x = z.x > 0.f ? g.x : 0.f; g.y = z.y > 0.f ? g.y : 0.f;
+            g.z = z.z > 0.f ? g.z : 0.f; g.w = z.w > 0.f ? g.w : 0.f;
+            st1[j] += g;
+            st2[j] += g * axv[q];
+          } else {
+            st1[j] += g;
+            st2[j] += g * g;
+          }
+          bst4(rO, obase + (unsigned)(8 * q * p.ldo * 4), EPA ? e0v * g + oldv[q] : g);
         }
       }
     }
   }
   if (p.stats) {
-    float* red = smem;   // [WM][2][BN]; every wave is past the last barrier above
+    // per-lane column-quad sums -> red[which][row group (WM * 8)][BN] -> one sum per column
+    constexpr int RG = WM * 8;
+    float* red = smem;
+    __syncthreads();                       // transposition images are dead
     if (ks == 0) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        float a = st1[j] + __shfl_xor(st1[j], 32, 64);
-        float b = st2[j] + __shfl_xor(st2[j], 32, 64);
-        if (lh == 0) {
-          const int c = (wn * TN + j) * 32 + li;
-          red[(wm * 2 + 0) * BN + c] = a;
-          red[(wm * 2 + 1) * BN + c] = b;
-        }
+        const int c = (wn * TN + j) * 32 + 4 * ecq;
+        *reinterpret_cast<f32x4*>(red + (0 * RG + wm * 8 + erow) * BN + c) = st1[j];
+        *reinterpret_cast<f32x4*>(red + (1 * RG + wm * 8 + erow) * BN + c) = st2[j];
       }
     }
     __syncthreads();
@@ -407,7 +420,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
       if (n0 + cc < p.N) {
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < WM; ++w) s += red[(w * 2 + which) * BN + cc];
+        for (int g = 0; g < RG; ++g) s += red[(which * RG + g) * BN + cc];
         p.stats_out[((long)tile_x * 2 + which) * p.N + n0 + cc] = s;
       }
     }
@@ -421,8 +434,11 @@ void launch_inst(const ConvGemmParams& p, hipStream_t s) {
   constexpr size_t b_elems = KMAJOR ? (size_t)BKT * (BN + 4) : (size_t)BN * (BKT + 4);
   constexpr size_t stage = (NBUF * (size_t)BM * (BKT + 4) + NBUF * b_elems) * sizeof(float);
   // the K-split combine and the statistics reduce reuse the staging area
-  constexpr size_t red = ((size_t)(KS - 1) * (BM / 32) * (BN / 32) * 16 * 64 + 2 * WM * BN) * sizeof(float);
-  constexpr size_t lds = stage > red ? stage : red;
+  constexpr size_t red = (size_t)(KS - 1) * (BM / 32) * (BN / 32) * 16 * 64 * sizeof(float);
+  constexpr size_t epi = (size_t)WM * WN * 32 * 36 * sizeof(float);      // epilogue transposition images
+  constexpr size_t sta = (size_t)2 * WM * 8 * BN * sizeof(float);        // statistics combine
+  constexpr size_t m1 = stage > red ? stage : red, m2 = epi > sta ? epi : sta;
+  constexpr size_t lds = m1 > m2 ? m1 : m2;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, KS, NBUF, PF, KIND>),

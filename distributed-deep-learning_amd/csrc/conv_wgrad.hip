@@ -107,6 +107,19 @@ __device__ __forceinline__ f32x4 pix_apply(const RawPix& r, const ColAffine& k) 
 
 constexpr int RK = 32;   // pixels per slab step
 
+// XCD-aware work order.  Workgroups are dealt round-robin over the 8 XCDs (one L2 each); the T
+// workgroups that share a pixel chunk (the channel tiles of the 1x1 kernel, the three filter rows of
+// the 3x3 kernel) re-read the same dO / activation rows, so they are given linear ids that agree
+// mod 8 and lie next to each other in time: id = lo + 8 * (t + T * hi), chunk = 8 * hi + lo.  The
+// second and later readers then hit that XCD's L2 instead of going back to HBM.
+__device__ __forceinline__ bool xcd_group(int id, int T, int S, int& t, int& chunk) {
+  const int lo = id & 7, rest = id >> 3;
+  const int hi = rest / T;
+  t = rest - hi * T;
+  chunk = hi * 8 + lo;
+  return chunk < S;
+}
+
 // ---------------------------------------------------------------------------------------------
 // 1x1: output tile 128 (n) x 128 (c) per workgroup, 2x2 waves of 64x64.
 // grid = (c tiles, n tiles, S)
@@ -119,8 +132,11 @@ __global__ void __launch_bounds__(256) wgrad1x1_kernel(const WgradParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int li = lane & 31, lh = lane >> 5;
-  const int c0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
-  const int mb = blockIdx.z * p.rows_per_wg;
+  const int ctiles = (p.C + 127) / 128, ntiles = (p.N + 127) / 128;
+  int t_idx, chunk;
+  if (!xcd_group(blockIdx.x, ctiles * ntiles, p.S, t_idx, chunk)) return;     // grid padded to 8 chunks
+  const int c0 = (t_idx % ctiles) * 128, n0 = (t_idx / ctiles) * 128;
+  const int mb = chunk * p.rows_per_wg;
   int me = mb + p.rows_per_wg;
   if (me > p.M) me = p.M;
   const int steps = (me - mb + RK - 1) / RK;
@@ -193,7 +209,7 @@ __global__ void __launch_bounds__(256) wgrad1x1_kernel(const WgradParams p) {
     __syncthreads();
   }
   // slab write: slabs[z][n][c]
-  float* slab = p.slabs + (long)blockIdx.z * p.N * p.C;
+  float* slab = p.slabs + (long)chunk * p.N * p.C;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -220,10 +236,13 @@ __global__ void __launch_bounds__(256) wgrad3x3_kernel(const WgradParams p) {
   int* Fl = reinterpret_cast<int*>(smem + 2 * RK * 32 + 2 * AR * 128);   // [2][RK]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int dy = (int)blockIdx.y - 1;
-  const int cbase = blockIdx.z * 128;
+  const int ctiles = (p.C + 127) / 128;
+  int t_idx, chunk;
+  if (!xcd_group(blockIdx.x, 3 * ctiles, p.S, t_idx, chunk)) return;          // grid padded to 8 chunks
+  const int dy = t_idx % 3 - 1;
+  const int cbase = (t_idx / 3) * 128;
   const int HW = p.H * p.W;
-  const int mb = blockIdx.x * p.rows_per_wg;
+  const int mb = chunk * p.rows_per_wg;
   int me = mb + p.rows_per_wg;
   if (me > p.M) me = p.M;
   const int steps = (me - mb + RK - 1) / RK;
@@ -306,7 +325,7 @@ __global__ void __launch_bounds__(256) wgrad3x3_kernel(const WgradParams p) {
     __syncthreads();
   }
   const int KC = 9 * p.C;
-  float* slab = p.slabs + (long)blockIdx.x * p.N * KC;
+  float* slab = p.slabs + (long)chunk * p.N * KC;
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     const int tap = (dy + 1) * 3 + t;
@@ -377,11 +396,11 @@ void launch_wgrad(const WgradParams& p, float* dW, hipStream_t s) {
   }
   const bool two = p.d.X1 != nullptr;
   if (p.taps == 1) {
-    dim3 grid((p.C + 127) / 128, (p.N + 127) / 128, p.S);
+    dim3 grid((unsigned)(((p.C + 127) / 128) * ((p.N + 127) / 128) * 8 * ((p.S + 7) / 8)));
     if (two) hipLaunchKernelGGL(wgrad1x1_kernel<true>, grid, dim3(256), lds1, s, p);
     else hipLaunchKernelGGL(wgrad1x1_kernel<false>, grid, dim3(256), lds1, s, p);
   } else {
-    dim3 grid(p.S, 3, (p.C + 127) / 128);
+    dim3 grid((unsigned)(3 * ((p.C + 127) / 128) * 8 * ((p.S + 7) / 8)));
     if (two) hipLaunchKernelGGL(wgrad3x3_kernel<true>, grid, dim3(256), lds3, s, p);
     else hipLaunchKernelGGL(wgrad3x3_kernel<false>, grid, dim3(256), lds3, s, p);
   }
