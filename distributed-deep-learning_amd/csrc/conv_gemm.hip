@@ -517,7 +517,7 @@ int pick_cfg(int M, int N, int force) {
     else if ((M + 63) / 64 >= 512) bm = 64;
     else return (M + 63) / 64 >= 256 ? 11 : 5;
   }
-  return bm == 128 ? 3 : bm == 64 ? 4 : 5;
+  return bm == 128 ? 9 : bm == 64 ? 10 : 5;      // single LDS buffer for the bigger tiles (B = 30 and 128 sweeps)
 }
 
 }  // namespace
