@@ -44,6 +44,38 @@ def split_sizes(batch: int, n: int) -> List[int]:
     return [base + (1 if i < rem else 0) for i in range(n)]
 
 
+class _GraphNode:
+    __slots__ = ("graph", "x", "t", "inp", "out", "loss")
+
+    def __init__(self) -> None:
+        self.graph = self.x = self.t = self.inp = self.out = self.loss = None
+
+
+class _GraphSet:
+    """The hipGraphs of one step shape: one per micro-batch forward and one per micro-batch backward,
+    captured in schedule order into one private memory pool and replayed in that same order (the
+    schedule is static, so the order never changes).  The stage's compute is ~770 launches per
+    micro-batch forward+backward of a few microseconds each - eager, a 5-micro-batch step is bound
+    by the host; captured, it is 2 launches per micro-batch.  P2P transfers stay outside the graphs
+    and move the graphs' static input / output buffers."""
+
+    def __init__(self, warmup: int) -> None:
+        self.warmup = warmup
+        self.steps = 0
+        self.active = False
+        self.fwd, self.bwd = {}, {}
+        self._pool = None
+
+    def begin_step(self) -> None:
+        self.active = self.steps >= self.warmup
+        self.steps += 1
+
+    def pool(self):
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        return self._pool
+
+
 class PipelineStage:
     """One stage of the pipeline on this rank.
 
@@ -54,7 +86,8 @@ class PipelineStage:
     def __init__(self, module: torch.nn.Module, stage_index: int, num_stages: int, device,
                  group=None, ranks: Optional[Sequence[int]] = None,
                  recv_shape_fn: Optional[Callable[[int], Tuple[int, ...]]] = None,
-                 dtype: torch.dtype = torch.float32, dp_engine=None) -> None:
+                 dtype: torch.dtype = torch.float32, dp_engine=None, hip_graph: bool = False,
+                 graph_warmup: int = 2) -> None:
         self.module = module
         self.stage_index = stage_index
         self.num_stages = num_stages
@@ -70,6 +103,11 @@ class PipelineStage:
         self.dp_engine = dp_engine
         self._act_slots = {}      # (mb_index, shape) -> recv buffer for forward activations
         self._grad_slots = {}     # (mb_index, shape) -> recv buffer for backward gradients
+        # hipGraph capture of the per-micro-batch forward / backward (see ``_GraphSet``)
+        self.hip_graph = bool(hip_graph) and self.device.type == "cuda"
+        self.graph_warmup = graph_warmup
+        self._graph_sets = {}     # signature of a step (micro-batch shapes, train/eval) -> _GraphSet
+        self._gs: Optional[_GraphSet] = None
         self.reset()
 
     def reset(self) -> None:
@@ -112,9 +150,84 @@ class PipelineStage:
         g = self.inputs.pop(i)
         return [dist.P2POp(dist.isend, g, self.prev_rank, self.group)]
 
-    # ---- compute -------------------------------------------------------------------------
+    # ---- hipGraph plumbing ---------------------------------------------------------------
+    def begin_step(self, signature) -> None:
+        """Called by the schedule before the first micro-batch: selects the graph set of this step
+        shape.  The first ``graph_warmup`` steps of a shape run eagerly, the next one captures every
+        forward / backward in schedule order (capture + replay in place), later steps only replay."""
+        self._gs = None
+        if not self.hip_graph:
+            return
+        gs = self._graph_sets.get(signature)
+        if gs is None:
+            gs = self._graph_sets[signature] = _GraphSet(self.graph_warmup)
+        gs.begin_step()
+        self._gs = gs if gs.active else None
+
     def forward(self, i: int, x: Optional[torch.Tensor], target: Optional[torch.Tensor],
                 loss_fn, train: bool) -> None:
+        gs = self._gs
+        if gs is None:
+            return self._forward_eager(i, x, target, loss_fn, train)
+        node = gs.fwd.get(i)
+        if node is None:
+            node = gs.fwd[i] = _GraphNode()
+            node.x = x.clone() if x is not None else None
+            node.t = target.clone() if target is not None else None
+            inp_slot = None if self.is_first else self.inputs[i]     # persistent receive slot
+            node.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(node.graph, pool=gs.pool(), capture_error_mode="thread_local"):
+                if not self.is_first:
+                    self.inputs[i] = inp_slot
+                self._forward_eager(i, node.x, node.t, loss_fn, train)
+            node.inp, node.out, node.loss = self.inputs.get(i), self.outputs[i], self.losses.get(i)
+        else:
+            if node.x is not None:
+                node.x.copy_(x, non_blocking=True)
+            if node.t is not None:
+                node.t.copy_(target, non_blocking=True)
+        node.graph.replay()
+        if not self.is_first:
+            self.inputs[i] = node.inp
+        self.outputs[i] = node.out
+        if node.loss is not None:
+            self.losses[i] = node.loss
+
+    def backward(self, i: int, scale: float, last: bool) -> None:
+        gs = self._gs
+        if gs is None:
+            return self._backward_eager(i, scale, last)
+        dp = self.dp_engine
+        node = gs.bwd.get(i)
+        if node is None:
+            node = gs.bwd[i] = _GraphNode()
+            if dp is not None:
+                dp.arm(False)                      # no collectives inside a capture
+            grad_slot = self.grads_in.get(i)
+            node.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(node.graph, pool=gs.pool(), capture_error_mode="thread_local"):
+                if grad_slot is not None:
+                    self.grads_in[i] = grad_slot
+                self._backward_eager(i, scale, False, arm=False)
+            node.inp = self.inputs.get(i)          # gradient w.r.t. the stage input (sent upstream)
+            node.out = self.outputs.get(i)
+        else:
+            self.grads_in.pop(i, None)
+            if self.is_last:
+                self.outputs[i] = node.out
+            else:
+                self.outputs.pop(i, None)
+        node.graph.replay()
+        if not self.is_first:
+            self.inputs[i] = node.inp
+        else:
+            self.inputs.pop(i, None)
+        if dp is not None and last:
+            dp.arm(True)                           # buckets are launched by finish_grad_sync()
+
+    # ---- compute -------------------------------------------------------------------------
+    def _forward_eager(self, i: int, x: Optional[torch.Tensor], target: Optional[torch.Tensor],
+                       loss_fn, train: bool) -> None:
         if self.is_first:
             inp = x
         else:
@@ -127,9 +240,9 @@ class PipelineStage:
         if self.is_last and loss_fn is not None:
             self.losses[i] = loss_fn(out, target)
 
-    def backward(self, i: int, scale: float, last: bool) -> None:
+    def _backward_eager(self, i: int, scale: float, last: bool, arm: bool = True) -> None:
         dp = self.dp_engine
-        if dp is not None:
+        if dp is not None and arm:
             dp.arm(last)
         if self.is_last:
             loss = self.losses[i]
@@ -216,6 +329,8 @@ class _ScheduleBase:
             raise RuntimeError("a schedule with a loss_fn cannot run under no_grad; "
                                "use a loss-less schedule for inference")
         st.reset()
+        st.begin_step((tuple(sizes), train, self.loss_fn is not None,
+                       tuple(x.shape[1:]) if x is not None else None))
         self.order = []
         self._run(xs, ts, sizes, train)
         out = None

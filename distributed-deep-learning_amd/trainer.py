@@ -229,7 +229,8 @@ class PPStrategy(Strategy):
 
         self.stage = PipelineStage(self.model, self.stage_index, S, self.device,
                                    group=mesh.get_group("pp"), ranks=mesh.pp_ranks,
-                                   recv_shape_fn=recv_shape, dp_engine=self.dp)
+                                   recv_shape_fn=recv_shape, dp_engine=self.dp,
+                                   hip_graph=cfg.hip_graph and native and self.device.type == "cuda")
         sched = SCHEDULES[cfg.schedule]
         # two schedules over one stage, like the reference (pp.py:138-150): training (with loss)
         # and loss-less inference for evaluation under no_grad

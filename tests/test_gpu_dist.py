@@ -110,7 +110,7 @@ def test_phased_graph_ddp_matches_eager():
     run_distributed(_phased_graph_worker, 2, timeout=300)
 
 
-def _pp_worker(rank, world, schedule):
+def _pp_worker(rank, world, schedule, graph):
     from ddl import comm, ops
     from ddl.models import create_stage
     from ddl.models.densenet import DenseNetStage
@@ -137,23 +137,29 @@ def _pp_worker(rank, world, schedule):
     want_grad = mine.arena.flat_grad.clone()
     want_out = torch.cat(outs)
     # undo the reference's side effects on BN buffers, then run the real pipeline
-    mine.arena.zero_grad()
-    st = PipelineStage(mine, rank, 2, dev, recv_shape_fn=lambda mb: (mb, 7, 7, 512))
+    st = PipelineStage(mine, rank, 2, dev, recv_shape_fn=lambda mb: (mb, 7, 7, 512), hip_graph=graph,
+                       graph_warmup=1)
     sched = SCHEDULES[schedule](st, n_mb, loss_fn=ops.cross_entropy)
-    if rank == 0:
-        out = sched.step(x)
-        assert out is None
-    else:
-        losses = []
-        out = sched.step(target=y, losses=losses)
-        torch.testing.assert_close(out, want_out, rtol=2e-4, atol=2e-5)
-        assert len(losses) == n_mb
-    torch.testing.assert_close(mine.arena.flat_grad, want_grad, rtol=2e-3, atol=2e-5)
+    # with hipGraphs: step 0 eager, step 1 captures every micro-batch forward/backward, step 2 replays
+    for step in range(3 if graph else 1):
+        mine.arena.zero_grad()
+        if rank == 0:
+            out = sched.step(x)
+            assert out is None
+        else:
+            losses = []
+            out = sched.step(target=y, losses=losses)
+            torch.testing.assert_close(out, want_out, rtol=2e-4, atol=2e-5)
+            assert len(losses) == n_mb
+        torch.testing.assert_close(mine.arena.flat_grad, want_grad, rtol=2e-3, atol=2e-5)
+    if graph:
+        gs = next(iter(st._graph_sets.values()))
+        assert len(gs.fwd) == n_mb and len(gs.bwd) == n_mb
 
 
-@pytest.mark.parametrize("schedule", ["1f1b", "gpipe"])
-def test_native_pipeline_two_stages_one_gpu(schedule):
-    run_distributed(_pp_worker, 2, schedule, timeout=300)
+@pytest.mark.parametrize("schedule,graph", [("1f1b", False), ("gpipe", False), ("1f1b", True), ("gpipe", True)])
+def test_native_pipeline_two_stages_one_gpu(schedule, graph):
+    run_distributed(_pp_worker, 2, schedule, graph, timeout=300)
 
 
 def _torchrun(n, script, args, tmp_path):
