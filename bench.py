@@ -43,6 +43,7 @@ def main() -> None:
     ap.add_argument("--bucket-mb", type=float, default=8.0)
     ap.add_argument("--zero1", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--backend", default="auto", help="auto = RCCL; gloo lets several ranks share one GPU (rehearsal only)")
     ap.add_argument("--profile", action="store_true", help="add the compute/RCCL breakdown to the JSON")
     a = ap.parse_args()
 
@@ -54,7 +55,7 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world > 1:
         a.gpus = world
-    ctx = comm.init("auto", "auto", force=True)
+    ctx = comm.init(a.backend, "auto", force=True)
     dev = ctx.device
     B = a.batch_per_gpu
     strategy_name = a.mode
