@@ -189,6 +189,59 @@ class HostLoader:
         return sizes
 
 
+class DevicePrefetcher:
+    """Host -> device staging one batch ahead on a dedicated copy stream.
+
+    The reference copies each fp32 batch synchronously from pageable memory right before it is used
+    (ddp.py:181-182).  Here the loader hands out pinned uint8 batches; while step ``i`` computes,
+    batch ``i + 1`` is already crossing PCIe on the copy stream, and the compute stream only waits on
+    an event.  Stages that need neither images nor labels (middle pipeline stages) copy nothing.
+    Batches that already live on the device (``DeviceSyntheticLoader``) pass straight through.
+    """
+
+    def __init__(self, loader, device, needs_input: bool = True, needs_target: bool = True) -> None:
+        self.loader, self.device = loader, torch.device(device)
+        self.needs_input, self.needs_target = needs_input, needs_target
+        self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+
+    def __len__(self) -> int:
+        return len(self.loader)
+
+    def _stage(self, batch):
+        x, y = batch
+        n = int(x.shape[0])
+        if self.stream is None:
+            return (x.to(self.device) if self.needs_input else None,
+                    y.to(self.device) if self.needs_target else None, n, None)
+        with torch.cuda.stream(self.stream):
+            xd = x.to(self.device, non_blocking=True) if self.needs_input else None
+            yd = y.to(self.device, non_blocking=True) if self.needs_target else None
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return xd, yd, n, ev
+
+    def __iter__(self):
+        """Yields ``(x_dev | None, y_dev | None, batch_size)``."""
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            xd, yd, n, ev = nxt
+            try:
+                nxt = self._stage(next(it))        # enqueue the next copy before handing out this batch
+            except StopIteration:
+                nxt = None
+            if ev is not None:
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                for t in (xd, yd):                 # allocated on the copy stream, consumed on the compute stream
+                    if t is not None and t.is_cuda:
+                        t.record_stream(cur)
+            yield xd, yd, n
+
+
 class DeviceSyntheticLoader:
     """Synthetic uint8 batches generated directly on the device (benchmark input)."""
 

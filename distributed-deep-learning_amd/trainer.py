@@ -29,6 +29,7 @@ import torch
 from . import checkpoint as ckpt
 from . import comm, metrics, ops
 from .config import TrainConfig
+from .data import DevicePrefetcher
 from .models import create_stage
 from .models.densenet import UNIT_NAMES, DenseNetStage, stage_units
 from .optim import FusedAdam
@@ -343,12 +344,6 @@ class Trainer:
         ckpt.save_snapshot(path, epoch, self.s.model, self.s.optimizer, self.s.ckpt_suffix)
         self._print(f"Epoch {epoch} | Saved snapshot to {path}")
 
-    def _to_device(self, x, y):
-        s = self.s
-        x = x.to(self.device, non_blocking=True) if s.needs_input else None
-        y = y.to(self.device, non_blocking=True) if s.needs_target else None
-        return x, y
-
     # ---- training ----------------------------------------------------------------------
     def _run_epoch(self, epoch: int) -> Tuple[int, int]:
         s, cfg = self.s, self.cfg
@@ -364,11 +359,10 @@ class Trainer:
             self._targets = torch.empty(cap, dtype=torch.int64, device=self.device)
             self._losses = torch.zeros(steps, dtype=torch.float32, device=self.device)
         seen = 0
-        for step, (x, y) in enumerate(self.train_data):
+        for step, (x, y, n) in enumerate(DevicePrefetcher(self.train_data, self.device, s.needs_input,
+                                                          s.needs_target)):
             if step >= steps:
                 break
-            n = int(x.shape[0])
-            x, y = self._to_device(x, y)
             res = s.train_step(x, y, n)
             if res is not None:
                 loss, _out, preds = res
@@ -431,11 +425,10 @@ class Trainer:
         s, cfg = self.s, self.cfg
         self.test_data.set_epoch(epoch)
         outs, tgts = [], []
-        for step, (x, y) in enumerate(self.test_data):
+        for step, (x, y, n) in enumerate(DevicePrefetcher(self.test_data, self.device, s.needs_input,
+                                                          s.needs_target)):
             if cfg.max_steps and step >= cfg.max_steps:
                 break
-            n = int(x.shape[0])
-            x, y = self._to_device(x, y)
             out = s.eval_step(x, y, n)
             if s.has_output:
                 outs.append(out)

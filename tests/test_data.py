@@ -51,3 +51,15 @@ def test_loaders_lengths_match_reference_epoch():
     assert len(te) == 12
     x, y = next(iter(tr))
     assert x.dtype == torch.uint8 and tuple(x.shape) == (15, 3, 224, 224) and y.dtype == torch.int64
+
+
+def test_device_prefetcher_order_and_roles():
+    """Prefetching one batch ahead must not reorder or drop batches; roles skip what a stage does not need."""
+    import torch
+    from ddl.data import DevicePrefetcher
+    batches = [(torch.full((3, 2), i, dtype=torch.uint8), torch.tensor([i, i, i])) for i in range(5)]
+    got = list(DevicePrefetcher(batches, "cpu"))
+    assert [int(x[0, 0]) for x, _, _ in got] == list(range(5)) and all(n == 3 for _, _, n in got)
+    got = list(DevicePrefetcher(batches, "cpu", needs_input=False))
+    assert all(x is None and int(y[0]) == i for i, (x, y, _) in enumerate(got))
+    assert list(DevicePrefetcher([], "cpu")) == []
