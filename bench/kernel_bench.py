@@ -42,7 +42,7 @@ def timeit(fn, iters=a.iters):
 
 
 cases = []
-NCFG = 18
+NCFG = 22
 
 
 def case(name, flops):

@@ -464,10 +464,11 @@ void launch_cfg(const ConvGemmParams& p, hipStream_t s) {
 // config (force - 1000) explicitly (bench/kernel_bench.py --cfg); 32/64/128 force the row-tile
 // height of the default family; 0 = heuristic.
 struct TileCfg { int bm, bn; };
-constexpr int NUM_CFG = 18;
+constexpr int NUM_CFG = 22;
 const TileCfg kCfg[NUM_CFG] = {{128, 128}, {64, 128}, {32, 128}, {128, 32}, {64, 32}, {32, 32},
                                {128, 128}, {64, 128}, {32, 128}, {128, 32}, {64, 32}, {32, 32},
-                               {128, 128}, {64, 128}, {32, 128}, {128, 32}, {64, 32}, {32, 32}};
+                               {128, 128}, {64, 128}, {32, 128}, {128, 32}, {64, 32}, {32, 32},
+                               {32, 32}, {32, 32}, {32, 128}, {64, 32}};
 
 void launch_by_id(int id, const ConvGemmParams& p, hipStream_t s) {
   switch (id) {
@@ -488,7 +489,11 @@ void launch_by_id(int id, const ConvGemmParams& p, hipStream_t s) {
     case 14: launch_cfg<32, 128, 1, 4, 2, 2, 2>(p, s); break;
     case 15: launch_cfg<128, 32, 4, 1, 1, 2, 2>(p, s); break;
     case 16: launch_cfg<64, 32, 2, 1, 2, 2, 2>(p, s); break;
-    default: launch_cfg<32, 32, 1, 1, 4, 2, 2>(p, s); break;
+    case 17: launch_cfg<32, 32, 1, 1, 4, 2, 2>(p, s); break;
+    case 18: launch_cfg<32, 32, 1, 1, 8, 1>(p, s); break;       // 8 / 16 waves on one 32-row tile: small-M layers
+    case 19: launch_cfg<32, 32, 1, 1, 16, 1>(p, s); break;      //   have < 1 workgroup per CU, so the K split supplies
+    case 20: launch_cfg<32, 128, 1, 4, 4, 1>(p, s); break;      //   the waves that overlap VALU staging with MFMA
+    default: launch_cfg<64, 32, 2, 1, 4, 1>(p, s); break;
   }
 }
 
@@ -503,7 +508,7 @@ int pick_cfg(int M, int N, int force) {
   int bm = (force == 32 || force == 64 || force == 128) ? force : 0;
   if (N > 32) {
     if (!bm && M <= 2048)
-      return ((long)((M + 63) / 64) * ((N + 31) / 32) >= 256) ? 4 : 5;
+      return ((long)((M + 63) / 64) * ((N + 31) / 32) >= 256) ? 4 : 18;
     if (!bm) {
       const long nt = (N + 127) / 128;
       if ((long)((M + 63) / 64) * nt >= 8192) bm = 128;
@@ -515,7 +520,7 @@ int pick_cfg(int M, int N, int force) {
   if (!bm) {
     if ((M + 127) / 128 >= 384) bm = 128;
     else if ((M + 63) / 64 >= 512) bm = 64;
-    else return (M + 63) / 64 >= 256 ? 11 : 5;
+    else return (M + 63) / 64 >= 256 ? 11 : 18;     // < 1 workgroup per CU: 8-way K split (2 waves / SIMD)
   }
   return bm == 128 ? 9 : bm == 64 ? 10 : 5;      // single LDS buffer for the bigger tiles (B = 30 and 128 sweeps)
 }
