@@ -52,6 +52,8 @@ class TrainConfig:
     impl: str = "auto"                  # auto | native | torch   (auto: native on GPU, torch on CPU)
     dtype: str = "fp32"                 # fp32 (reference parity) | bf16 (mixed: bf16 MFMA inputs)
     hip_graph: bool = True              # capture the native train step into a hipGraph
+    pretrained: Optional[str] = field(default_factory=lambda: os.environ.get("DDL_PRETRAINED") or None)
+    #   ^ torchvision densenet121 state-dict file (reference: weights=IMAGENET1K_V1, single.py:297)
     # ---- data parallel -------------------------------------------------------
     bucket_mb: float = 8.0              # gradient bucket size (MiB); sized for xGMI, not NVSwitch
     grad_sync: str = "rs_ag"            # rs_ag (reduce-scatter + all-gather) | allreduce
@@ -129,7 +131,7 @@ def build_parser(script: str) -> argparse.ArgumentParser:
             p.add_argument(flag, type=_str2bool, nargs="?", const=True, default=default)
         elif f.name in ("seed", "snapshot_epoch"):
             p.add_argument(flag, type=int, default=default)
-        elif f.name == "snapshot_job_id":
+        elif f.name in ("snapshot_job_id", "pretrained"):
             p.add_argument(flag, type=str, default=default)
         else:
             p.add_argument(flag, type=type(default), default=default)

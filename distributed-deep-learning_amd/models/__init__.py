@@ -19,14 +19,21 @@ def resolve_impl(impl: str, device) -> str:
 
 
 def create_stage(units: Sequence[str], device, impl: str = "auto", num_classes: int = 5,
-                 dtype: str = "fp32", **native_kw) -> torch.nn.Module:
+                 dtype: str = "fp32", pretrained: str = None, **native_kw) -> torch.nn.Module:
     """A contiguous run of DenseNet-121 units on ``device``.
 
     ``impl='torch'``: plain PyTorch ops (CPU plumbing path; numerics oracle).
     ``impl='native'``: the hand-written HIP engine (NHWC, flat arena, fused BN/ReLU/conv)."""
     impl = resolve_impl(impl, device)
     if impl == "torch":
-        return DenseNetStage(units, num_classes).to(device)
-    from .native_densenet import NativeDenseNetStage
+        stage = DenseNetStage(units, num_classes).to(device)
+    else:
+        from .native_densenet import NativeDenseNetStage
 
-    return NativeDenseNetStage(units, num_classes=num_classes, device=device, dtype=dtype, **native_kw)
+        stage = NativeDenseNetStage(units, num_classes=num_classes, device=device, dtype=dtype, **native_kw)
+    if pretrained:
+        # reference: densenet121(weights=IMAGENET1K_V1) + a fresh Linear(1024, classes) (single.py:297-299)
+        from .pretrained import load_pretrained
+
+        load_pretrained(stage, pretrained)
+    return stage

@@ -116,7 +116,8 @@ class SingleStrategy(Strategy):
 
     def __init__(self, cfg, ctx) -> None:
         super().__init__(cfg, ctx)
-        self.model = create_stage(UNIT_NAMES, self.device, cfg.impl, cfg.num_classes, cfg.dtype)
+        self.model = create_stage(UNIT_NAMES, self.device, cfg.impl, cfg.num_classes, cfg.dtype,
+                                  pretrained=cfg.pretrained)
         self.arena = _arena_for(self.model, self.device, cfg.bucket_mb, 1)
         self.optimizer = self._make_optimizer(self.arena)
         self.global_rank = self.local_rank = 0          # single.py:269 hard-codes 0,0
@@ -140,7 +141,7 @@ class DDPStrategy(Strategy):
     def __init__(self, cfg, ctx, group=None) -> None:
         super().__init__(cfg, ctx)
         self.model = create_stage(UNIT_NAMES, self.device, cfg.impl, cfg.num_classes, cfg.dtype,
-                                  **self._native_kw(cfg, comm.get_world_size(group)))
+                                  pretrained=cfg.pretrained, **self._native_kw(cfg, comm.get_world_size(group)))
         self.dp = DataParallelEngine(self.model, group=group, device=self.device, bucket_mb=cfg.bucket_mb,
                                      grad_sync=cfg.grad_sync, sync_buffers=cfg.sync_buffers,
                                      zero1=cfg.zero1, profiler=self.profiler, debug_sync=cfg.debug_sync)
@@ -193,7 +194,8 @@ class PPStrategy(Strategy):
                              f"but the pipeline group has {S} ranks")
         self.units = units_per_stage[self.stage_index]
         nat = dict(bucket_mb=cfg.bucket_mb, dp_world=mesh.dp_size) if cfg.impl != "torch" else {}
-        self.model = create_stage(self.units, self.device, cfg.impl, cfg.num_classes, cfg.dtype, **nat)
+        self.model = create_stage(self.units, self.device, cfg.impl, cfg.num_classes, cfg.dtype,
+                                  pretrained=cfg.pretrained, **nat)
         hybrid = mesh.dp_size > 1
         self.name = "ddpnpp" if hybrid else "pp"
         if hybrid:

@@ -62,3 +62,34 @@ def test_uint8_input_is_normalised():
     m = dn.densenet121(5).eval()
     x = torch.randint(0, 256, (1, 3, 64, 64), dtype=torch.uint8)
     torch.testing.assert_close(m(x), m(x.float() / 255.0))
+
+
+def test_pretrained_file_loading(tmp_path):
+    """--pretrained: a torchvision-style 1000-class state-dict (incl. legacy 'norm.1' key names) initialises
+    features; the ImageNet classifier is discarded like in the reference (single.py:297-299); pipeline
+    stages pick up only their own keys."""
+    import torch
+    from ddl.models import create_stage
+    from ddl.models.densenet import UNIT_NAMES, DenseNetStage
+    from ddl.models.pretrained import normalise_keys, read_state_dict
+    torch.manual_seed(0)
+    src = DenseNetStage(UNIT_NAMES, 1000)
+    sd = {}
+    for k, v in src.state_dict().items():
+        k = k.replace("denselayer2.norm1.", "denselayer2.norm.1.").replace("denselayer2.conv2.", "denselayer2.conv.2.")
+        sd["module." + k] = v
+    path = str(tmp_path / "densenet121.pth")
+    torch.save({"state_dict": sd}, path)
+    assert "features.denseblock1.denselayer2.norm1.weight" in read_state_dict(path)
+    assert normalise_keys({"a.denselayer3.conv.1.weight": torch.zeros(1)}).keys() == {"a.denselayer3.conv1.weight"}
+    torch.manual_seed(1)
+    full = create_stage(UNIT_NAMES, "cpu", "torch", 5, pretrained=path)
+    ref = src.state_dict()
+    for k, v in full.state_dict().items():
+        if k.startswith("classifier."):
+            assert tuple(v.shape) in ((5, 1024), (5,))
+        else:
+            torch.testing.assert_close(v, ref[k], rtol=0, atol=0)
+    stage = create_stage(("denseblock3", "transition3"), "cpu", "torch", 5, pretrained=path)
+    k = "features.denseblock3.denselayer7.conv1.weight"
+    torch.testing.assert_close(stage.state_dict()[k], ref[k], rtol=0, atol=0)
