@@ -83,3 +83,17 @@ def test_zero1_shard_updates_only_its_slice():
         half = (seg.end - seg.start) // 2
         assert not changed[seg.start:seg.start + half].any()
         assert changed[seg.start + half:seg.end].all()
+
+
+def test_arena_break_before_starts_a_new_segment():
+    """Segments can be forced to start at named parameters (the native engine aligns gradient buckets
+    with the phases of its chained backward graphs), and stay divisible for reduce-scatter."""
+    import torch
+    from ddl.utils.arena import FlatArena
+    ps = [(f"p{i}", torch.nn.Parameter(torch.randn(100 + i))) for i in range(6)]
+    a = FlatArena(ps, segment_numel=10_000, segment_multiple=4 * 64, break_before=["p2", "p5", "p0"])
+    assert [[a.names[i] for i in seg.slots] for seg in a.segments] == [["p0", "p1"], ["p2", "p3", "p4"], ["p5"]]
+    assert all((seg.end - seg.start) % (4 * 64) == 0 for seg in a.segments)
+    assert [s.segment for s in a.slots] == [0, 0, 1, 1, 1, 2]
+    for (n, p), s in zip(ps, a.slots):
+        assert p.data_ptr() == a.flat_param[s.offset:].data_ptr()
