@@ -55,6 +55,8 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world > 1:
         a.gpus = world
+    if world > 1:
+        a.profile = True      # event-based compute / RCCL / exposed-communication split (no host sync in the loop)
     ctx = comm.init(a.backend, "auto", force=True)
     dev = ctx.device
     B = a.batch_per_gpu
