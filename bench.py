@@ -64,12 +64,15 @@ def main() -> None:
     pp_size = a.pp_size if a.mode != "ddp" else 1
     if a.mode == "pp":
         pp_size = world
-    cfg = TrainConfig(strategy=strategy_name, batch_size=B, impl=a.impl, dtype=a.dtype,
-                      bucket_mb=a.bucket_mb, zero1=a.zero1, hip_graph=not a.no_graph,
-                      num_microbatches=a.microbatches, schedule=a.schedule, pp_size=pp_size,
-                      split_points=default_split_points(max(pp_size, 1)), profile=a.profile,
-                      sync_buffers="forward", num_workers=0)
-    strat = build_strategy(cfg, ctx)
+    def make_strategy(hip_graph: bool):
+        cfg = TrainConfig(strategy=strategy_name, batch_size=B, impl=a.impl, dtype=a.dtype,
+                          bucket_mb=a.bucket_mb, zero1=a.zero1, hip_graph=hip_graph,
+                          num_microbatches=a.microbatches, schedule=a.schedule, pp_size=pp_size,
+                          split_points=default_split_points(max(pp_size, 1)), profile=a.profile,
+                          sync_buffers="forward", num_workers=0)
+        return build_strategy(cfg, ctx)
+
+    strat = make_strategy(not a.no_graph)
     dp = strat.dp_size
 
     g = torch.Generator().manual_seed(1234 + ctx.rank)
@@ -85,9 +88,24 @@ def main() -> None:
             torch.cuda.synchronize(dev)
 
     strat.model.train()
-    for i in range(a.warmup):
-        x, y = pool[i % len(pool)]
-        strat.train_step(x, y, B)
+    try:
+        for i in range(a.warmup):
+            x, y = pool[i % len(pool)]
+            strat.train_step(x, y, B)
+        graph_mode = "off" if a.no_graph else "hipGraph"
+    except Exception as e:      # noqa: BLE001 - e.g. a capture refused by the runtime: measure the eager path instead
+        if a.no_graph:
+            raise
+        print(f"[rank {ctx.rank}] hipGraph path failed during warm-up ({type(e).__name__}: {e}); "
+              f"falling back to eager launches", file=sys.stderr, flush=True)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        strat = make_strategy(False)
+        strat.model.train()
+        for i in range(a.warmup):
+            x, y = pool[i % len(pool)]
+            strat.train_step(x, y, B)
+        graph_mode = "eager (fallback)"
     strat.profiler.reset()
     sync()
     t0 = time.perf_counter()
@@ -129,6 +147,7 @@ def main() -> None:
                             f"pp{pp_size}" if a.mode == "pp" else f"dp{dp}xpp{pp_size}"),
             "baseline": f"{base_key} {BASELINE[base_key]} samples/s (BASELINE.md sec. 2)",
             "impl": impl,
+            "launch": graph_mode,
             "grad_sync": "zero1 rs+ag(params)" if a.zero1 else "bucketed reduce-scatter + all-gather",
         },
     }
