@@ -16,14 +16,11 @@
 //    rows, each thread a fixed float4 channel column, so per-channel sums stay in registers and
 //    one LDS pass combines the row lanes.
 #include "ddl_kernels.h"
+#include "device_utils.h"
 
 namespace ddl {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 namespace {
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 // sum partials[g][which][c] over g for 32 channels with the 32 slices of a 1024-thread workgroup;
 // loads are issued 4 deep (independent accumulators) so the table read is not one long dependent chain

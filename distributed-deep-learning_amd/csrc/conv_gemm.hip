@@ -32,37 +32,11 @@
 // limiting; what matters is keeping every SIMD's MFMA queue fed.
 #include "conv_params.h"
 #include "ddl_kernels.h"
+#include "device_utils.h"
 
 namespace ddl {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 namespace {
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-
-// Buffer (SRD) addressing: 32-bit byte offsets against a wave-uniform descriptor with hardware bounds
-// checking - an out-of-range offset loads 0 and drops stores.  Every "is this row / tap / column
-// valid" decision becomes a select between the real offset and OOB, so the operand loads and the
-// epilogue are straight-line code (the branchy flat-address form spent ~10x more instructions on
-// addressing than on MFMA issue and serialised its loads behind vmcnt(0) waits).
-constexpr unsigned OOB = 0x80000000u;     // beyond any descriptor: views are < 2 GiB (checked on the host)
-__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ f32x4 bld4(rsrc_t r, unsigned off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
-}
-__device__ __forceinline__ float bld1(rsrc_t r, unsigned off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
-}
-__device__ __forceinline__ void bst4(rsrc_t r, unsigned off, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)off, 0, 0);
-}
 
 // Operation kinds (what DenseNet needs; anything else is rejected on the host):
 //   0 FWD     one source, n-major weights, plain store            (+ column statistics v, v*v)

@@ -18,27 +18,11 @@
 // floats per half-wave - conflict-free ds_read_b32.
 #include "conv_params.h"
 #include "ddl_kernels.h"
+#include "device_utils.h"
 
 namespace ddl {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 namespace {
-
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-
-// Buffer (SRD) addressing, as in conv_gemm.hip: 32-bit byte offsets, hardware bounds check, an
-// invalid row / column selects the OOB offset (loads 0) - the staging loads are straight-line code.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-constexpr unsigned OOB = 0x80000000u;
-__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ f32x4 bld4(rsrc_t r, unsigned off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
-}
 
 // Per-thread operand column state: a thread always stages the same channel quad, so the affine
 // vectors are fetched once; pixel data is fetched raw one step ahead and transformed only when it

@@ -15,16 +15,11 @@
 // shift: it stages the 40-pixel input run of a 16-output-pixel segment once and reads the im2col
 // matrix as an overlapping view (row stride 8 floats) straight out of LDS.
 #include "ddl_kernels.h"
+#include "device_utils.h"
 
 namespace ddl {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 namespace {
-
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 constexpr int KP = 224;          // padded GEMM K: 7 filter rows x (8 pixels x 4 channels)
 constexpr int NC0 = 64;          // conv0 output channels
@@ -68,7 +63,8 @@ constexpr int FBM = 128, FLD = 36;
 __global__ void __launch_bounds__(256) stem_conv_fwd_kernel(const float* __restrict__ xp,
                                                             const float* __restrict__ wp,
                                                             float* __restrict__ y0, float* __restrict__ stats,
-                                                            int M, int H, int W, int H0, int W0) {
+                                                            int M, int H, int W, int H0, int W0,
+                                                            unsigned xp_bytes) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                       // [2][FBM][FLD]
   float* Bs = smem + 2 * FBM * FLD;       // [2][NC0][FLD]
@@ -83,29 +79,31 @@ __global__ void __launch_bounds__(256) stem_conv_fwd_kernel(const float* __restr
   }
   const long m0 = (long)tile_x * FBM;
   const int aq = tid & 7, a_row0 = tid >> 3;
-  long a_base[4];
-  int a_iy0[4], a_ix[4];
+  // buffer addressing (device_utils.h): invalid rows / padding pixels select the OOB offset
+  const rsrc_t rX = make_rsrc(xp, xp_bytes);
+  unsigned a_base[4];
+  int a_iy0[4];
   bool a_ok[4];
   const int HW0 = H0 * W0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const long m = m0 + a_row0 + 32 * i;
-    const long b = m / HW0;
-    const int rem = (int)(m - b * HW0);
+    const int m = (int)m0 + a_row0 + 32 * i;
+    const int b = m / HW0;
+    const int rem = m - b * HW0;
     const int oy = rem / W0, ox = rem - oy * W0;
-    a_base[i] = b * H * W;
+    const int ix = 2 * ox - 3 + aq;
     a_iy0[i] = 2 * oy - 3;
-    a_ix[i] = 2 * ox - 3 + aq;
-    a_ok[i] = m < M && a_ix[i] >= 0 && a_ix[i] < W;
+    a_base[i] = (unsigned)((b * H + a_iy0[i]) * W + ix) * 16u;      // byte offset of filter row 0 (may wrap: unused then)
+    a_ok[i] = m < M && ix >= 0 && ix < W;
   }
+  const unsigned row_bytes = (unsigned)W * 16u;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 a_reg[4], b_reg[2];
   auto load_slab = [&](int ky) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int iy = a_iy0[i] + ky;
-      a_reg[i] = zero4;
-      if (a_ok[i] && iy >= 0 && iy < H) a_reg[i] = ld4(xp + (a_base[i] + (long)iy * W + a_ix[i]) * 4);
+      a_reg[i] = bld4(rX, (a_ok[i] && iy >= 0 && iy < H) ? a_base[i] + (unsigned)ky * row_bytes : OOB);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -319,6 +317,9 @@ __global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict
   const int steps = (seg_e - seg_b + 1) / 2;
   const int segs_per_img = H0 * XS;
 
+  const unsigned y_bytes = (unsigned)(nseg / XS) * (unsigned)W0 * NC0 * 4u;       // B*H0*W0*64 floats
+  const rsrc_t rG = make_rsrc(g0, y_bytes), rY = make_rsrc(y0, y_bytes);
+  const rsrc_t rX = make_rsrc(xp, (unsigned)(nseg / segs_per_img) * (unsigned)(H * W) * 16u);
   const int dq = 4 * (tid & 15);
   const f32x4 c0 = ld4(k0 + dq), c1 = ld4(k1 + dq), c2 = ld4(k2 + dq);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -330,38 +331,30 @@ __global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict
     for (int i = 0; i < 2; ++i) {     // dY0 tile: 32 rows x 16 float4
       const int r = (tid >> 4) + 16 * i;          // == segment i of the step, pixel (tid >> 4)
       const int seg = s0 + i;
-      d_ok[i] = false;
-      d_g[i] = zero4;
-      d_y[i] = zero4;
-      if (seg < seg_e) {
+      {
         const int b = seg / segs_per_img;
         const int rem = seg - b * segs_per_img;
         const int oy = rem / XS, xs = rem - oy * XS;
         const int ox = xs * SEG + (r & 15);
-        if (ox < W0) {
-          const long m = ((long)b * H0 + oy) * W0 + ox;
-          d_ok[i] = true;
-          d_g[i] = ld4(g0 + m * NC0 + dq);
-          d_y[i] = ld4(y0 + m * NC0 + dq);
-        }
+        d_ok[i] = seg < seg_e && ox < W0;
+        const unsigned off = d_ok[i] ? (unsigned)(((b * H0 + oy) * W0 + ox) * NC0 + dq) * 4u : OOB;
+        d_g[i] = bld4(rG, off);
+        d_y[i] = bld4(rY, off);
       }
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {     // input runs: 7 filter rows x 2 segments x 40 pixels
       const int f = tid + i * 256;
-      r_reg[i] = zero4;
-      if (f < 7 * 2 * 40) {
+      {
         const int ky = f / 80, rem80 = f - ky * 80;
         const int sg = rem80 / 40, j = rem80 - sg * 40;
         const int seg = s0 + sg;
-        if (seg < seg_e) {
-          const int b = seg / segs_per_img;
-          const int rem = seg - b * segs_per_img;
-          const int oy = rem / XS, xs = rem - oy * XS;
-          const int iy = 2 * oy + ky - 3, ix = 2 * xs * SEG - 3 + j;
-          if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-            r_reg[i] = ld4(xp + (((long)b * H + iy) * W + ix) * 4);
-        }
+        const int b = seg / segs_per_img;
+        const int rem = seg - b * segs_per_img;
+        const int oy = rem / XS, xs = rem - oy * XS;
+        const int iy = 2 * oy + ky - 3, ix = 2 * xs * SEG - 3 + j;
+        const bool ok = f < 7 * 2 * 40 && seg < seg_e && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        r_reg[i] = bld4(rX, ok ? (unsigned)((b * H + iy) * W + ix) * 16u : OOB);
       }
     }
   };
@@ -531,8 +524,9 @@ void launch_stem_conv_fwd(const float* xp, const float* wp, float* y0, float* st
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
+  const unsigned xp_bytes = (unsigned)((M0 / ((long)H0 * W0)) * H * W * 16);      // < 2 GiB: checked by the binding
   hipLaunchKernelGGL(stem_conv_fwd_kernel, dim3(stem_conv_grid(M0)), dim3(256), lds, s, xp, wp, y0, stats,
-                     (int)M0, H, W, H0, W0);
+                     (int)M0, H, W, H0, W0, xp_bytes);
 }
 
 void launch_stem_pool_fwd(const float* y0, const float* sc, const float* sh, float* p, uint8_t* idx, int B,
