@@ -16,6 +16,7 @@ ap.add_argument("--batch", type=int, default=30)
 ap.add_argument("--only", default=None)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--bm", type=int, default=0)
+ap.add_argument("--bf16", action="store_true", help="bf16 MFMA inputs for the conv_gemm cases")
 ap.add_argument("--min-rows", type=int, default=64, help="wgrad: minimum pixel rows per workgroup")
 ap.add_argument("--sweep", action="store_true", help="time every conv_gemm tile config per case")
 ap.add_argument("--cfg", type=int, default=-1, help="explicit conv_gemm tile config id (csrc/conv_gemm.hip)")
@@ -74,22 +75,22 @@ for (blk, H, Cl, Cf) in [("b1", 56, 160, 256), ("b2", 28, 320, 512), ("b3", 14, 
 
     def f1(M=M, buf=buf, Cl=Cl, sc=sc, sh=sh, w1=w1, out=out128, H=H):
         ext.conv_gemm(buf[:, :Cl], None, sc, None, sh, True, M, H, H, 1, False, w1, False, out, False, False,
-                      None, None, None, 1, a.bm)
+                      None, None, None, 1, a.bm, a.bf16)
     cases.append((f"{blk}_fwd1x1_K{Cl}", 2.0 * M * Cl * 128, f1))
 
     def f2(M=M, h=h, sc=sc, sh=sh, w2=w2, buf=buf, Cl=Cl, H=H):
         ext.conv_gemm(h, None, sc, None, sh, True, M, H, H, 9, False, w2, False, buf[:, Cl:Cl + 32], False, False,
-                      None, None, None, 1, a.bm)
+                      None, None, None, 1, a.bm, a.bf16)
     cases.append((f"{blk}_fwd3x3", 2.0 * M * 1152 * 32, f2))
 
     def f3(M=M, dbuf=dbuf, buf=buf, Cl=Cl, ones=ones, sc=sc, sh=sh, w2=w2, g2=g2, h=h, H=H):
         ext.conv_gemm(dbuf[:, Cl:Cl + 32], buf[:, Cl:Cl + 32], ones[:32], sc[:32], sh[:32], False, M, H, H, 9, True,
-                      w2, True, g2, True, False, h, sc, sh, 2, a.bm)
+                      w2, True, g2, True, False, h, sc, sh, 2, a.bm, a.bf16)
     cases.append((f"{blk}_dgrad3x3", 2.0 * M * 1152 * 32, f3))
 
     def f4(M=M, g2=g2, h=h, k=k, w1=w1, dbuf=dbuf, buf=buf, Cl=Cl, sc=sc, sh=sh, H=H):
         ext.conv_gemm(g2, h, k[0], k[1], k[2], False, M, H, H, 1, False, w1, True, dbuf[:, :Cl], True, True,
-                      buf[:, :Cl], sc, sh, 2, a.bm)
+                      buf[:, :Cl], sc, sh, 2, a.bm, a.bf16)
     cases.append((f"{blk}_dgrad1x1_N{Cl}", 2.0 * M * Cl * 128, f4))
 
     def f5(M=M, g2=g2, h=h, k=k, buf=buf, Cl=Cl, sc=sc, sh=sh, gw1=gw1, H=H):

@@ -59,7 +59,7 @@ ddl::RowSrc make_src(const at::Tensor& x0, const OptT& x1, const OptT& s0, const
 at::Tensor conv_gemm(const at::Tensor& x0, const OptT& x1, const OptT& s0, const OptT& s1, const OptT& s2,
                      bool relu, int64_t M, int64_t H, int64_t W, int64_t taps, bool flip,
                      const at::Tensor& weight, bool b_kmajor, at::Tensor out, bool ep_mask, bool ep_accum,
-                     const OptT& aux, const OptT& e0, const OptT& e1, int64_t stats_mode, int64_t force_bm) {
+                     const OptT& aux, const OptT& e0, const OptT& e1, int64_t stats_mode, int64_t force_bm, bool bf16) {
   ddl::DeviceGuard guard(x0.device());
   const int64_t C = x0.size(1), N = out.size(1);
   TORCH_CHECK(taps == 1 || taps == 9, "taps must be 1 or 9");
@@ -90,6 +90,7 @@ at::Tensor conv_gemm(const at::Tensor& x0, const OptT& x1, const OptT& s0, const
   TORCH_CHECK(stats_mode >= 0 && stats_mode <= 2, "stats_mode");
   if (stats_mode == 2) { TORCH_CHECK(p.aux, "stats_mode 2 needs aux"); }
   p.stats = (int)stats_mode;
+  p.bf16 = bf16 ? 1 : 0;
   // operation kind: the combinations DenseNet uses (conv_gemm.hip)
   const bool two = x1.has_value();
   if (!two && !b_kmajor && !ep_mask && !ep_accum && stats_mode != 2) p.kind = 0;
@@ -240,7 +241,12 @@ at::Tensor bnrelu_gap_fwd(const at::Tensor& x, int64_t B, int64_t HW, const at::
 }  // namespace
 
 void register_conv_ops(pybind11::module_& m) {
-  m.def("conv_gemm", &conv_gemm, "implicit-GEMM conv (1x1 / 3x3) with fused prologue + epilogue");
+  m.def("conv_gemm", &conv_gemm, "implicit-GEMM conv (1x1 / 3x3) with fused prologue + epilogue",
+        pybind11::arg("x0"), pybind11::arg("x1"), pybind11::arg("s0"), pybind11::arg("s1"), pybind11::arg("s2"),
+        pybind11::arg("relu"), pybind11::arg("M"), pybind11::arg("H"), pybind11::arg("W"), pybind11::arg("taps"),
+        pybind11::arg("flip"), pybind11::arg("weight"), pybind11::arg("b_kmajor"), pybind11::arg("out"),
+        pybind11::arg("ep_mask"), pybind11::arg("ep_accum"), pybind11::arg("aux"), pybind11::arg("e0"),
+        pybind11::arg("e1"), pybind11::arg("stats_mode"), pybind11::arg("force_bm"), pybind11::arg("bf16") = false);
   m.def("conv_wgrad", &conv_wgrad, "conv weight gradient (split-M slabs + deterministic reduce)");
   m.def("bn_prep", &bn_prep, "finalize channel statistics, derive BN scale/shift, update running stats");
   m.def("bn_bwd_prep", &bn_bwd_prep, "BN backward per-channel coefficients, dgamma/dbeta");

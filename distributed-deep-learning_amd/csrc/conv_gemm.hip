@@ -43,9 +43,16 @@ namespace {
 //   1 TDGRAD  one source, k-major weights, plain store            (transition data gradient)
 //   2 DGRAD3  two sources, k-major, masked store                  (+ statistics g, g*aux)
 //   3 DGRAD1  two sources, k-major, masked accumulate into out    (+ statistics g, g*aux)
-template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF, int KIND>
+//
+// BF = true: bf16 matrix-core inputs, fp32 accumulate (`--dtype bf16`).  Storage stays fp32; the
+// operands are rounded (RNE, v_cvt_pk_bf16_f32) when they are written to LDS, after the fused
+// BN/ReLU prologue, and consumed by v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).  Both LDS
+// images are then K-contiguous bf16 rows of 2*BKT + 16 bytes (conflict-free ds_read_b128); k-major
+// weights are transposed while being staged, so the MFMA loop is the same for every kind.
+template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF, int KIND, bool BF>
 __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const ConvGemmParams p) {
   constexpr bool TWO = KIND >= 2, KMAJOR = KIND >= 1, EPM = KIND >= 2, EPA = KIND == 3;
+  constexpr int LDH = 32 * KS + 8;       // bf16 image row stride (elements)
   constexpr int NT = 64 * WM * WN * KS;
   constexpr int TM = BM / (32 * WM);
   constexpr int TN = BN / (32 * WN);
@@ -66,6 +73,8 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                        // [NBUF][BM][LDA]
   float* Bs = smem + NBUF * BM * LDA;      // [NBUF][B_ELEMS]
+  __bf16* Ah = reinterpret_cast<__bf16*>(smem);       // BF: [NBUF][BM][LDH]
+  __bf16* Bh = Ah + NBUF * BM * LDH;                  //     [NBUF][BN][LDH]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int ks = wid / (WM * WN);
@@ -190,6 +199,8 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
   auto store_slab = [&](int buf, const Stage& S) {
     float* Ab = As + buf * BM * LDA;
     float* Bb = Bs + buf * B_ELEMS;
+    __bf16* Ahb = Ah + buf * BM * LDH;
+    __bf16* Bhb = Bh + buf * BN * LDH;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       f32x4 v = S.a_v0[i];
@@ -201,11 +212,20 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
         }
         if (!((S.a_mask >> i) & 1u)) v = zero4;
       }
-      *reinterpret_cast<f32x4*>(Ab + (a_row0 + i * RSTEP) * LDA + 4 * aq) = v;
+      if (BF) *reinterpret_cast<bf16x4*>(Ahb + (a_row0 + i * RSTEP) * LDH + 4 * aq) = __builtin_convertvector(v, bf16x4);
+      else *reinterpret_cast<f32x4*>(Ab + (a_row0 + i * RSTEP) * LDA + 4 * aq) = v;
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      if (!KMAJOR) {
+      if (BF) {
+        const bf16x4 h = __builtin_convertvector(S.b_reg[i], bf16x4);
+        if (!KMAJOR) {
+          *reinterpret_cast<bf16x4*>(Bhb + (a_row0 + i * RSTEP) * LDH + 4 * aq) = h;
+        } else {             // transpose on the way in: this thread holds 4 output channels of one k
+          __bf16* q = Bhb + 4 * (tid - bk_row * BQ4) * LDH + (bk_row + i * KROWS);
+          q[0] = h[0]; q[LDH] = h[1]; q[2 * LDH] = h[2]; q[3 * LDH] = h[3];
+        }
+      } else if (!KMAJOR) {
         *reinterpret_cast<f32x4*>(Bb + (a_row0 + i * RSTEP) * LDA + 4 * aq) = S.b_reg[i];
       } else {
         *reinterpret_cast<f32x4*>(Bb + (bk_row + i * KROWS) * LDBK + 4 * (tid - bk_row * BQ4)) = S.b_reg[i];
@@ -222,6 +242,26 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto compute = [&](int buf) {
+    if (BF) {
+      const __bf16* Ab = Ah + buf * BM * LDH + (wm * TM * 32 + li) * LDH + ks * 32 + 8 * lh;
+      const __bf16* Bb = Bh + buf * BN * LDH + (wn * TN * 32 + li) * LDH + ks * 32 + 8 * lh;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {        // two 16-wide k steps per 32-wide sub-slab
+        bf16x8 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * LDH + 16 * s);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * LDH + 16 * s);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (n0 + (wn * TN + j) * 32 >= p.N) continue;
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      return;
+    }
     const float* Ab = As + buf * BM * LDA + (wm * TM * 32 + li) * LDA + ks * 32 + 4 * lh;
     const float* Bb = Bs + buf * B_ELEMS;
 #pragma unroll
@@ -401,7 +441,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
   }
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF, int KIND>
+template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF, int KIND, bool BF>
 void launch_inst(const ConvGemmParams& p, hipStream_t s) {
   constexpr bool KMAJOR = KIND >= 1;
   constexpr int BKT = 32 * KS;
@@ -415,22 +455,31 @@ void launch_inst(const ConvGemmParams& p, hipStream_t s) {
   constexpr size_t lds = m1 > m2 ? m1 : m2;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, KS, NBUF, PF, KIND>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, KS, NBUF, PF, KIND, BF>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.N + BN - 1) / BN));
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, KS, NBUF, PF, KIND>), grid, dim3(64 * WM * WN * KS), lds, s, p);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, KS, NBUF, PF, KIND, BF>), grid, dim3(64 * WM * WN * KS), lds, s, p);
 }
 
 template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF = 1>
 void launch_cfg(const ConvGemmParams& p, hipStream_t s) {
   static_assert(PF == 1 || NBUF == 2, "prefetch distance 2 needs both LDS buffers");
+  if (p.bf16) {
+    switch (p.kind) {
+      case 0: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 0, true>(p, s); break;
+      case 1: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 1, true>(p, s); break;
+      case 2: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 2, true>(p, s); break;
+      default: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 3, true>(p, s); break;
+    }
+    return;
+  }
   switch (p.kind) {
-    case 0: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 0>(p, s); break;
-    case 1: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 1>(p, s); break;
-    case 2: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 2>(p, s); break;
-    default: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 3>(p, s); break;
+    case 0: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 0, false>(p, s); break;
+    case 1: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 1, false>(p, s); break;
+    case 2: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 2, false>(p, s); break;
+    default: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 3, false>(p, s); break;
   }
 }
 

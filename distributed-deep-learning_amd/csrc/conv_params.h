@@ -49,6 +49,7 @@ struct ConvGemmParams {
   float* stats_out;   // [gridDim.x][2][N]
   // derived on the host (conv_bindings.cpp: finish_params)
   int kind;           // 0 FWD, 1 TDGRAD, 2 DGRAD3, 3 DGRAD1 (see conv_gemm.hip)
+  int bf16;           // 1: bf16 MFMA inputs (rounded at the LDS write), fp32 accumulate
   int inv_cc;         // ceil(2^16 / (C / 32)): sub-slab index -> (tap, channel chunk) without a division
   unsigned wbytes, obytes, auxbytes;   // extents of weight / out / aux in bytes
 };

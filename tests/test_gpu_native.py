@@ -60,6 +60,69 @@ def test_conv3x3_fwd_slice_write(dev, B, H, W, bm):
     torch.testing.assert_close(st[:, 0].sum(0).double(), ref.sum(0), rtol=1e-4, atol=1e-2)
 
 
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+def _assert_bf16_close(got, ref):
+    """A prologue value within one fp32 ulp of a bf16 rounding boundary may round the other way in the kernel
+    (fma contraction), moving single outputs by ~|w| * 2^-8 * |a|: judge the tensor in L2, bound the outliers."""
+    got, ref = got.double(), ref.double()
+    assert float((got - ref).norm() / ref.norm().clamp_min(1e-12)) < 2e-4
+    assert float((got - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("M,C,N,Cf,bm", [(300, 64, 128, 256, 0), (3136, 96, 128, 256, 128), (1000, 224, 128, 256, 64),
+                                          (94, 992, 128, 1024, 0), (1470, 768, 128, 1024, 1018)])
+def test_conv1x1_fwd_bf16(dev, M, C, N, Cf, bm):
+    """--dtype bf16: operands are rounded to bf16 AFTER the fused BN+ReLU prologue, products accumulate in
+    fp32 - so the result must match an fp64 GEMM of the bf16-rounded operands to fp32-accumulation accuracy."""
+    from ddl import ops
+    ext = ops.require_ext()
+    buf = _rand(M, Cf, dev=dev, seed=1)
+    sc, sh = _rand(Cf, dev=dev, seed=2).abs() + 0.5, _rand(Cf, dev=dev, seed=3)
+    w = _rand(N, C, dev=dev, seed=4, scale=0.1)
+    out = torch.full((M, N), float("nan"), device=dev)
+    st = ext.conv_gemm(buf[:, :C], None, sc, None, sh, True, M, 1, 1, 1, False, w, False, out, False, False,
+                       None, None, None, 1, bm, True)
+    a = torch.relu(buf[:, :C] * sc[:C] + sh[:C])           # fp32 prologue, like the kernel
+    ref = _bf16_round(a) @ _bf16_round(w).t()
+    _assert_bf16_close(out, ref)
+    torch.testing.assert_close(st[:, 0].sum(0).double(), ref.sum(0), rtol=1e-3, atol=5e-2)
+
+
+@pytest.mark.parametrize("B,H,W,bm", [(2, 14, 14, 0), (3, 7, 7, 32), (1, 56, 56, 128), (5, 28, 28, 64)])
+def test_conv3x3_bf16_fwd_and_dgrad(dev, B, H, W, bm):
+    """bf16 3x3 forward (n-major weights) and data gradient (the same weights read k-major: transposed while
+    being staged) against fp64 convolutions of the bf16-rounded operands."""
+    from ddl import ops
+    from ddl.models.native_densenet import NativeDenseNetStage
+    ext = ops.require_ext()
+    M, C, N = B * H * W, 128, 32
+    h = _rand(M, C, dev=dev, seed=1)
+    sc, sh = _rand(C, dev=dev, seed=2).abs() + 0.5, _rand(C, dev=dev, seed=3)
+    w = _rand(N, C, 3, 3, dev=dev, seed=4, scale=0.05)
+    wn = NativeDenseNetStage._to_native(w)
+    out = torch.zeros(M, N, device=dev)
+    ext.conv_gemm(h, None, sc, None, sh, True, M, H, W, 9, False, wn, False, out, False, False, None, None, None,
+                  1, bm, True)
+    a = torch.relu(h * sc + sh)
+    a64 = _bf16_round(a).view(B, H, W, C).permute(0, 3, 1, 2)
+    ref = F.conv2d(a64, _bf16_round(w), padding=1).permute(0, 2, 3, 1).reshape(M, N)
+    _assert_bf16_close(out, ref)
+    # data gradient: g2 = mask(conv_transpose(dy)), two-source dy = 1*d + q*x + p
+    d, x = _rand(M, N, dev=dev, seed=5), _rand(M, N, dev=dev, seed=6)
+    q, pp = _rand(N, dev=dev, seed=7, scale=0.1), _rand(N, dev=dev, seed=8, scale=0.1)
+    ones = torch.ones(N, device=dev)
+    g2 = torch.zeros(M, C, device=dev)
+    ext.conv_gemm(d, x, ones, q, pp, False, M, H, W, 9, True, wn, True, g2, True, False, h, sc, sh, 2, bm, True)
+    dy = d + q * x + pp
+    dy64 = _bf16_round(dy).view(B, H, W, N).permute(0, 3, 1, 2)
+    gref = F.conv_transpose2d(dy64, _bf16_round(w), padding=1).permute(0, 2, 3, 1).reshape(M, C)
+    gref = torch.where((h * sc + sh).double() > 0, gref, torch.zeros_like(gref))
+    _assert_bf16_close(g2, gref)
+
+
 def _ref_stage(units, dev, seed=0):
     from ddl.models.densenet import DenseNetStage
     torch.manual_seed(seed)
