@@ -61,6 +61,7 @@ class _BlockFn(torch.autograd.Function):
     def forward(ctx, x_in: torch.Tensor, anchor: torch.Tensor, unit: "BlockUnit"):
         ext = _ext()
         train = unit.stage.training
+        bf = unit.stage.bf16
         B, H, W, C0 = x_in.shape
         L, Cf = unit.num_layers, unit.c_out
         M = B * H * W
@@ -81,12 +82,12 @@ class _BlockFn(torch.autograd.Function):
             ext.bn_prep(part if train else None, new0, n_new, float(M), stats[0], stats[1], stats[2],
                         lay.g1, lay.b1, lay.rm1, lay.rv1, sc1[l], sh1[l], C, BN_MOMENTUM, BN_EPS, train)
             st = ext.conv_gemm(buf2d[:, :C], None, sc1[l], None, sh1[l], True, M, H, W, 1, False,
-                               lay.w1, False, h[l], False, False, None, None, None, 1 if train else 0, 0)
+                               lay.w1, False, h[l], False, False, None, None, None, 1 if train else 0, 0, bf)
             ext.bn_prep(st if train else None, 0, MID, float(M), bn2[l, 0], bn2[l, 1], bn2[l, 2],
                         lay.g2, lay.b2, lay.rm2, lay.rv2, bn2[l, 3], bn2[l, 4], MID, BN_MOMENTUM, BN_EPS, train)
             part = ext.conv_gemm(h[l], None, bn2[l, 3], None, bn2[l, 4], True, M, H, W, 9, False,
                                  lay.w2, False, buf2d[:, C:C + GROWTH], False, False, None, None, None,
-                                 1 if train else 0, 0)
+                                 1 if train else 0, 0, bf)
             new0, n_new = C, GROWTH
         if train:   # statistics of the last slice (consumed by the following transition / head)
             ext.bn_prep(part, new0, n_new, float(M), stats[0], stats[1], stats[2], None, None, None, None,
@@ -122,6 +123,7 @@ class _BlockFn(torch.autograd.Function):
         g2 = torch.empty(2, M, MID, **f32)
         done = [None, None]
         min_rows = unit.stage.wgrad_min_rows
+        bf = unit.stage.bf16
         for l in range(L - 1, -1, -1):
             lay = unit.layers[l]
             C = C0 + GROWTH * l
@@ -136,7 +138,7 @@ class _BlockFn(torch.autograd.Function):
                 ev0.record(main)
             # 3x3 data gradient (+ ReLU/BN2 mask, sum g2, sum g2*h)
             st = ext.conv_gemm(dy, xs, ones[:GROWTH], nq[sl], np_[sl], False, M, H, W, 9, True,
-                               lay.w2, True, g2[par], True, False, h[l], sc2, sh2, 2, 0)
+                               lay.w2, True, g2[par], True, False, h[l], sc2, sh2, 2, 0, bf)
             # 3x3 weight gradient
             if side is not None:
                 side.wait_event(ev0)
@@ -163,7 +165,7 @@ class _BlockFn(torch.autograd.Function):
                                True, M, H, W, 1, lay.gw1, min_rows)
             # 1x1 data gradient: dh = k0*g2 + k1*h + k2 on the fly; epilogue: mask, dBuf += sc1*g1, sums
             st1 = ext.conv_gemm(g2[par], h[l], k[par, 0], k[par, 1], k[par, 2], False, M, H, W, 1, False,
-                                lay.w1, True, d2d[:, :C], True, True, buf2d[:, :C], sc1[l], sh1[l], 2, 0)
+                                lay.w1, True, d2d[:, :C], True, True, buf2d[:, :C], sc1[l], sh1[l], 2, 0, bf)
             ext.bn_bwd_prep(st1, float(M), stats[0], stats[2], sc1[l], lay.gg1, lay.gb1, None, nq, np_, C, 1)
         if side is not None:
             main.wait_stream(side)
@@ -244,7 +246,7 @@ class _TransitionFn(torch.autograd.Function):
         ext.rows_op(1, Mp, pooled, buf2d, ss[0], ss[1], pooled, H, W, False)
         y = torch.empty(B, H // 2, W // 2, Co, **f32)
         ext.conv_gemm(pooled, None, None, None, None, False, Mp, H // 2, W // 2, 1, False, unit.w, False,
-                      y.view(Mp, Co), False, False, None, None, None, 0, 0)
+                      y.view(Mp, Co), False, False, None, None, None, 0, 0, unit.stage.bf16)
         ctx.unit = unit
         ctx.geom = (B, H, W, C)
         ctx.save_for_backward(buf, stats, ss, pooled)
@@ -264,7 +266,7 @@ class _TransitionFn(torch.autograd.Function):
                        unit.gw, unit.stage.wgrad_min_rows)
         dpool = torch.empty(Mp, C, **f32)
         ext.conv_gemm(dy2d, None, None, None, None, False, Mp, H // 2, W // 2, 1, False, unit.w, True,
-                      dpool, False, False, None, None, None, 0, 0)
+                      dpool, False, False, None, None, None, 0, 0, unit.stage.bf16)
         dbuf = torch.empty(B, H, W, C, **f32)
         d2d = dbuf.view(M, C)
         st = ext.rows_op(2, M, dpool, buf2d, ss[0], ss[1], d2d, H, W, True)
@@ -411,8 +413,12 @@ class NativeDenseNetStage(nn.Module):
                  dtype: str = "fp32", bucket_mb: float = 8.0, dp_world: int = 1,
                  wgrad_min_rows: int = 64, grad_phases: Sequence[str] = ()) -> None:
         super().__init__()
-        if dtype != "fp32":
-            raise NotImplementedError("the native engine is fp32 (reference parity); bf16 MFMA mode is not built yet")
+        if dtype not in ("fp32", "bf16"):
+            raise ValueError(f"dtype must be fp32 or bf16, got {dtype!r}")
+        # bf16: the dense-block / transition forward and data-gradient GEMMs feed the bf16 MFMA (operands
+        # rounded at the LDS write, fp32 accumulate); storage, BN statistics, weight gradients, stem, head
+        # and Adam stay fp32.  Not the reference's numerics -- never the default, never the headline.
+        self.bf16 = dtype == "bf16"
         ops.require_ext()
         device = torch.device(device)
         if device.type != "cuda":
