@@ -95,6 +95,12 @@ def is_dist() -> bool:
     return dist.is_available() and dist.is_initialized()
 
 
+def force_collectives() -> bool:
+    """``DDL_FORCE_COLLECTIVES=1``: a world of one still issues its (trivial) collectives - rehearsal of the
+    RCCL code path on a one-GPU box."""
+    return os.environ.get("DDL_FORCE_COLLECTIVES", "0") == "1"
+
+
 def get_rank(group=None) -> int:
     return dist.get_rank(group) if is_dist() else 0
 

@@ -50,6 +50,9 @@ class DataParallelEngine:
         self.group = group
         self.world = comm.get_world_size(group) if comm.is_dist() else 1
         self.rank = comm.get_rank(group) if comm.is_dist() else 0
+        # DDL_FORCE_COLLECTIVES=1: issue every collective even in a world of one (a one-GPU box can then drive
+        # the real RCCL path - comm stream, fences, phased graphs - end to end; tests/test_gpu_dist.py)
+        self.single = self.world == 1 and not (comm.is_dist() and comm.force_collectives())
         self.device = torch.device(device) if device is not None else next(module.parameters()).device
         self.grad_sync = grad_sync
         self.sync_buffers_policy = sync_buffers
@@ -92,13 +95,13 @@ class DataParallelEngine:
     # ------------------------------------------------------------------ state sync
     def broadcast_state(self) -> None:
         """Rank-0 parameters and buffers win (DDP ctor semantics)."""
-        if self.world == 1:
+        if self.single:
             return
         comm.broadcast(self.arena.flat_param, self.src_global, self.group)
         self.broadcast_buffers(include_int=True)
 
     def broadcast_buffers(self, include_int: bool = False) -> None:
-        if self.world == 1:
+        if self.single:
             return
         if self.buffers.flat_float.numel():
             comm.broadcast(self.buffers.flat_float, self.src_global, self.group)
@@ -155,7 +158,7 @@ class DataParallelEngine:
         if self._launched[k] or not self._armed:
             return
         self._launched[k] = True
-        if self.world == 1:
+        if self.single:
             return
         seg = self.arena.segments[k]
         grad = self.arena.flat_grad[seg.start:seg.end]
@@ -216,7 +219,7 @@ class DataParallelEngine:
 
     def post_step(self) -> None:
         """ZeRO-1: all-gather the freshly updated parameter shards."""
-        if not self.zero1 or self.world == 1:
+        if not self.zero1 or self.single:
             return
 
         def run():

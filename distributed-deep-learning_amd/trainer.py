@@ -158,7 +158,7 @@ class DDPStrategy(Strategy):
         if cfg.impl == "torch":
             return {}
         # phased backward graphs (utils/graph.py) only matter when there is something to overlap with
-        phases = tuple(u for u in cfg.grad_phases.split(",") if u) if (world > 1 and cfg.hip_graph) else ()
+        phases = tuple(u for u in cfg.grad_phases.split(",") if u) if ((world > 1 or comm.force_collectives()) and cfg.hip_graph) else ()
         return dict(bucket_mb=cfg.bucket_mb, dp_world=world, grad_phases=phases)
 
     def train_step(self, x, y, batch_size):

@@ -42,7 +42,7 @@ class GraphedTrainStep:
         self.model, self.optimizer, self.dp, self.profiler = model, optimizer, dp, profiler
         self.warmup = warmup
         self.enabled = enabled
-        self.distributed = dp is not None and dp.world > 1
+        self.distributed = dp is not None and not dp.single
         self._seen: Dict[Tuple, int] = {}
         self._graphs: Dict[Tuple, _Captured] = {}
         self._pool = None

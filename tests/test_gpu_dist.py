@@ -192,3 +192,22 @@ def test_entry_scripts_on_gpu_shared_device(tmp_path):
     out = _torchrun(1, "communication_time.py", ["--iters", "3", "--max-bytes", "65536",
                                                   "--log-dir", str(tmp_path / "logs")], tmp_path)
     assert "all_reduce" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--zero1"], ["--no-graph"]])
+def test_bench_rccl_world_of_one_forced_collectives(tmp_path, extra):
+    """The driver's multi-GPU launch line with one rank: RCCL process group, DDL_FORCE_COLLECTIVES=1 makes the
+    world of one issue every bucket reduce-scatter / all-gather and buffer broadcast, so the phased hipGraph
+    chain + comm-stream fences run against the real RCCL (not the gloo rehearsal transport)."""
+    import json
+    os.environ["DDL_FORCE_COLLECTIVES"] = "1"
+    try:
+        out = _torchrun(1, "bench.py", ["--gpus", "1", "--steps", "6", "--warmup", "4", "--batch-per-gpu", "8",
+                                        "--profile", *extra], tmp_path)
+    finally:
+        os.environ.pop("DDL_FORCE_COLLECTIVES", None)
+    rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0
+    assert rec["config"]["launch"] == ("off" if "--no-graph" in extra else "hipGraph"), out[-3000:]
+    assert rec["profile"]["rccl_ms_per_step"] > 0, rec["profile"]
