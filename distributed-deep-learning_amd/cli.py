@@ -30,7 +30,7 @@ def run_training(script: str, argv: Optional[List[str]] = None) -> Trainer:
         comm.enable_checker()
     strategy = build_strategy(cfg, ctx)
     train_loader, test_loader = build_loaders(cfg, dp_rank=strategy.dp_rank, dp_size=strategy.dp_size,
-                                              device=ctx.device)
+                                              device=ctx.device, needs_input=strategy.needs_input)
     trainer = Trainer(strategy, train_loader, test_loader, cfg)
     trainer.train(cfg.epochs)
     if comm.is_dist():

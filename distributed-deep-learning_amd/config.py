@@ -38,6 +38,8 @@ class TrainConfig:
     batch_size: int = 30                # per-process batch (single 30, ddp 15, pp 30, ddpnpp 10)
     num_workers: int = 2
     device_data: bool = False           # generate synthetic batches directly on the GPU (benchmarks)
+    cache_dataset: str = "auto"         # auto | device | off: decode once, keep the uint8 dataset in HBM (data.ResidentLoader)
+    cache_budget_gb: float = 16.0       # auto: largest dataset (GB of uint8) kept resident
     eval_all: bool = False              # reference drops the eval tail (ddp.py:353); keep for parity
     # ---- optimisation (reference: optim.Adam defaults, single.py:108,305) ----
     epochs: int = 30

@@ -209,8 +209,8 @@ class DevicePrefetcher:
 
     def _stage(self, batch):
         x, y = batch
-        n = int(x.shape[0])
-        if self.stream is None:
+        n = int((x if x is not None else y).shape[0])
+        if self.stream is None or (y.is_cuda and (x is None or x.is_cuda)):    # CPU run / device-resident batch
             return (x.to(self.device) if self.needs_input else None,
                     y.to(self.device) if self.needs_target else None, n, None)
         with torch.cuda.stream(self.stream):
@@ -269,12 +269,109 @@ class DeviceSyntheticLoader:
         return [self.batch_size] * self.steps
 
 
+class ResidentLoader:
+    """The whole dataset decoded ONCE and kept in HBM as uint8; every later epoch is an index gather.
+
+    The reference decodes every PNG again in every epoch (DataLoader workers -> ``read_image`` -> /255 ->
+    fp32 -> pageable H2D copy, single.py:45-65,160-167).  APTOS at 224x224 is 3,662 x 150 KB = 0.55 GB as
+    uint8 - 0.2 % of one MI355X's 288 GB - and the transform is deterministic (no augmentation), so the
+    natural home of the dataset is the GPU: after the fill, an epoch involves no host I/O, no decode, no
+    PCIe traffic and no DataLoader workers; a batch is ``index_select`` by the epoch's sampler order
+    (same ``ShardedSampler`` contract: reshuffled by ``set_epoch``, sharded over the dp replicas).
+
+    Fill: with a process group every rank decodes a contiguous 1/W slice and the slices are all-gathered
+    (RCCL over xGMI; uint8), so start-up decode time also drops by W.
+    """
+
+    def __init__(self, dataset: Dataset, batch_size: int, sampler: ShardedSampler, device,
+                 num_workers: int = 2, drop_last: bool = True, needs_input: bool = True,
+                 shard_fill: bool = True, chunk: int = 256) -> None:
+        from . import comm
+        self.batch_size, self.sampler, self.drop_last = batch_size, sampler, drop_last
+        self.device = torch.device(device)
+        n = len(dataset)
+        world = comm.get_world_size() if (shard_fill and comm.is_dist()) else 1
+        rank = comm.get_rank() if world > 1 else 0
+        per = -(-n // world)
+        lo, hi = min(rank * per, n), min((rank + 1) * per, n)
+        c, h, w = dataset[0][0].shape
+        self.images = torch.empty((n, c, h, w), dtype=torch.uint8, device=self.device) if needs_input else None
+        self.labels = torch.empty(n, dtype=torch.int64, device=self.device)
+        chunk = min(chunk, per)
+        pin = self.device.type == "cuda"
+        it = iter(DataLoader(torch.utils.data.Subset(dataset, range(lo, hi)), batch_size=chunk, shuffle=False,
+                             num_workers=num_workers if hi - lo > chunk else 0, collate_fn=_collate_uint8,
+                             pin_memory=pin)) if hi > lo else iter(())
+        self.fill_decoded = hi - lo
+        for k in range(-(-per // chunk)):              # same number of rounds on every rank
+            xb, yb = next(it, (None, None))
+            m = 0 if xb is None else int(xb.shape[0])
+            if m and xb.dtype != torch.uint8:
+                raise TypeError("ResidentLoader caches raw uint8 images (dataset transform must be None)")
+            if world == 1:
+                if m:
+                    if needs_input:
+                        self.images[k * chunk:k * chunk + m].copy_(xb, non_blocking=True)
+                    self.labels[k * chunk:k * chunk + m].copy_(yb, non_blocking=True)
+                continue
+            xs = torch.zeros((chunk, c, h, w), dtype=torch.uint8, device=self.device)
+            ys = torch.zeros(chunk, dtype=torch.int64, device=self.device)
+            if m:
+                xs[:m].copy_(xb, non_blocking=True)
+                ys[:m].copy_(yb, non_blocking=True)
+            gx, gy = comm.all_gather_flat(xs), comm.all_gather_flat(ys)
+            for r in range(world):                      # rank r's k-th chunk covers [r*per + k*chunk, ...)
+                a = r * per + k * chunk
+                b = min(a + chunk, (r + 1) * per, n)
+                if b > a:
+                    if needs_input:
+                        self.images[a:b].copy_(gx[r * chunk:r * chunk + (b - a)])
+                    self.labels[a:b].copy_(gy[r * chunk:r * chunk + (b - a)])
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
+    @property
+    def nbytes(self) -> int:
+        return (self.images.numel() if self.images is not None else 0) + 8 * self.labels.numel()
+
+    def set_epoch(self, epoch: int) -> None:
+        self.sampler.set_epoch(epoch)
+
+    def batch_sizes(self) -> List[int]:
+        full, rem = divmod(len(self.sampler), self.batch_size)
+        return [self.batch_size] * full + ([rem] if rem and not self.drop_last else [])
+
+    def __len__(self) -> int:
+        return len(self.batch_sizes())
+
+    def __iter__(self):
+        order = torch.tensor(list(self.sampler), dtype=torch.int64).to(self.device, non_blocking=True)
+        a = 0
+        for m in self.batch_sizes():
+            idx = order[a:a + m]
+            a += m
+            x = self.images.index_select(0, idx) if self.images is not None else None
+            yield x, self.labels.index_select(0, idx)
+
+
 def use_synthetic(cfg) -> bool:
     if cfg.synthetic == "on":
         return True
     if cfg.synthetic == "off":
         return False
     return not (Path(cfg.data_dir) / "train.csv").exists()
+
+
+def resident_fits(cfg, n_samples: int, device) -> bool:
+    """``--cache-dataset``: ``device`` forces the HBM-resident loader, ``off`` the host DataLoader; ``auto`` picks
+    the resident loader on a GPU when the uint8 dataset fits ``--cache-budget-gb`` (default 16 of 288 GB)."""
+    if cfg.cache_dataset == "off" or device is None:
+        return False
+    if cfg.cache_dataset == "device":
+        return True
+    if torch.device(device).type != "cuda":
+        return False
+    return n_samples * 3 * cfg.image_size * cfg.image_size <= cfg.cache_budget_gb * 2 ** 30
 
 
 def build_datasets(cfg, transform=None):
@@ -294,7 +391,8 @@ def build_datasets(cfg, transform=None):
     return train, test
 
 
-def build_loaders(cfg, dp_rank: int = 0, dp_size: int = 1, device=None, shared_order: bool = False):
+def build_loaders(cfg, dp_rank: int = 0, dp_size: int = 1, device=None, shared_order: bool = False,
+                  needs_input: bool = True):
     """Train/eval loaders for one process.
 
     ``shared_order`` (pipeline stages): every rank iterates the *same* permutation
@@ -317,6 +415,10 @@ def build_loaders(cfg, dp_rank: int = 0, dp_size: int = 1, device=None, shared_o
                           drop_last=not cfg.eval_all)
     # reference: train DataLoader drop_last only in pp/hybrid (pp.py:366-372); single/ddp keep the tail
     drop_train = cfg.strategy in ("pp", "ddpnpp")
+    drop_test = (cfg.strategy in ("pp", "ddpnpp")) and not cfg.eval_all
+    if resident_fits(cfg, len(train_ds) + len(test_ds), device):
+        return (ResidentLoader(train_ds, cfg.batch_size, tr_s, device, cfg.num_workers, drop_train, needs_input),
+                ResidentLoader(test_ds, cfg.batch_size, te_s, device, cfg.num_workers, drop_test, needs_input))
     train = HostLoader(train_ds, cfg.batch_size, tr_s, cfg.num_workers, drop_last=drop_train, pin_memory=pin)
     test = HostLoader(test_ds, cfg.batch_size, te_s, cfg.num_workers,
                       drop_last=(cfg.strategy in ("pp", "ddpnpp")) and not cfg.eval_all, pin_memory=pin)
@@ -328,7 +430,11 @@ def make_png_dataset(root, n_train: int, n_test: int, image_size: int = 32, num_
     the real ``AptosDataset`` path without the private data."""
     root = Path(root)
     for split, n, col in (("train", n_train, "new_id_code"), ("test", n_test, "id_code")):
-        ds = SyntheticAptos(n, image_size, num_classes, seed=seed + (split == "test"))
+        ds = SyntheticAptos(n, image_size, num_classes, seed=seed)
+        if split == "test":            # same class templates, disjoint noise / labels (as build_datasets does)
+            ds.seed = seed + 1
+            g = torch.Generator().manual_seed(seed * 31 + 5)
+            ds.labels = torch.randint(0, num_classes, (n,), generator=g).tolist()
         os.makedirs(root / f"{split}_images", exist_ok=True)
         with open(root / f"{split}.csv", "w", newline="") as f:
             w = csv.writer(f)

@@ -63,3 +63,44 @@ def test_device_prefetcher_order_and_roles():
     got = list(DevicePrefetcher(batches, "cpu", needs_input=False))
     assert all(x is None and int(y[0]) == i for i, (x, y, _) in enumerate(got))
     assert list(DevicePrefetcher([], "cpu")) == []
+
+
+def _resident_cfg(**kw):
+    return TrainConfig(strategy="ddp", batch_size=4, synthetic="on", num_workers=0, image_size=16,
+                       train_samples=37, eval_samples=10, **kw)
+
+
+def test_resident_loader_equals_host_loader():
+    """--cache-dataset device: same batches in the same order as the DataLoader path, epoch after epoch."""
+    host = data.build_loaders(_resident_cfg(cache_dataset="off"), dp_rank=1, dp_size=2, device="cpu")
+    res = data.build_loaders(_resident_cfg(cache_dataset="device"), dp_rank=1, dp_size=2, device="cpu")
+    assert isinstance(res[0], data.ResidentLoader) and isinstance(host[0], data.HostLoader)
+    assert not isinstance(data.build_loaders(_resident_cfg(), device="cpu")[0], data.ResidentLoader)   # auto: GPU only
+    for h, r in zip(host, res):
+        assert len(h) == len(r) and h.batch_sizes() == r.batch_sizes()
+        for epoch in (0, 1):
+            h.set_epoch(epoch), r.set_epoch(epoch)
+            for (hx, hy), (rx, ry) in zip(h, r):
+                assert torch.equal(hx, rx) and torch.equal(hy, ry)
+    # a stage that needs no images caches labels only
+    lab = data.build_loaders(_resident_cfg(cache_dataset="device"), device="cpu", needs_input=False)[0]
+    assert lab.images is None and next(iter(lab))[0] is None and lab.nbytes == 8 * 37
+
+
+def _resident_fill_worker(rank, world):
+    from ddl import data
+    cfg = _resident_cfg(cache_dataset="device")
+    tr, _ = data.build_loaders(cfg, dp_rank=rank, dp_size=world, device="cpu")
+    assert tr.fill_decoded == (13 if rank < 2 else 11)            # ceil(37 / 3) each, last rank the rest
+    ds, _ = data.build_datasets(cfg)
+    small = data.ResidentLoader(ds, 4, data.ShardedSampler(len(ds), world, rank), "cpu", num_workers=0, chunk=5)
+    for i in range(len(ds)):                                      # several all-gather rounds, ragged last chunk
+        x, y = ds[i]
+        assert torch.equal(tr.images[i], x) and int(tr.labels[i]) == y
+        assert torch.equal(small.images[i], x) and int(small.labels[i]) == y
+
+
+def test_resident_loader_sharded_fill_gloo():
+    """With a process group every rank decodes 1/W of the dataset and the slices are all-gathered."""
+    from dist_utils import run_distributed
+    run_distributed(_resident_fill_worker, 3)
