@@ -87,22 +87,35 @@ def main() -> None:
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
 
+    # Priming (set-up, never timed, independent of --warmup): RCCL communicator creation, allocator growth
+    # and the hipGraph capture (2 eager steps + the capturing step) must not land in the timed region even
+    # when the driver asks for fewer warm-up steps than that.
+    PRIME = 3
     strat.model.train()
+    failure = None
     try:
-        for i in range(a.warmup):
+        for i in range(PRIME + a.warmup):
             x, y = pool[i % len(pool)]
             strat.train_step(x, y, B)
         graph_mode = "off" if a.no_graph else "hipGraph"
     except Exception as e:      # noqa: BLE001 - e.g. a capture refused by the runtime: measure the eager path instead
         if a.no_graph:
             raise
+        failure = e
+    if world > 1 and not a.no_graph:          # every rank takes the same path (a capture failure is symmetric)
+        flag = torch.tensor([0.0 if failure is None else 1.0], device=dev)
+        comm.all_reduce(flag, "max")
+        if flag.item() > 0 and failure is None:
+            failure = RuntimeError("another rank failed in the hipGraph path")
+    if failure is not None:
+        e = failure
         print(f"[rank {ctx.rank}] hipGraph path failed during warm-up ({type(e).__name__}: {e}); "
               f"falling back to eager launches", file=sys.stderr, flush=True)
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
         strat = make_strategy(False)
         strat.model.train()
-        for i in range(a.warmup):
+        for i in range(PRIME + a.warmup):
             x, y = pool[i % len(pool)]
             strat.train_step(x, y, B)
         graph_mode = "eager (fallback)"

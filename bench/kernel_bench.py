@@ -83,6 +83,22 @@ for (blk, H, Cl, Cf) in [("b1", 56, 160, 256), ("b2", 28, 320, 512), ("b3", 14, 
                       None, None, None, 1, a.bm, a.bf16)
     cases.append((f"{blk}_fwd3x3", 2.0 * M * 1152 * 32, f2))
 
+    acc_in = (torch.rand(8, 2, Cf, device=dev) * 2 ** 25 * M).long()
+    acc_in[:, 1] += acc_in[:, 0]                 # sum of squares >= sum: a valid (mean, var) pair
+    acc_out = torch.zeros(8, 2, 128, dtype=torch.int64, device=dev)
+    tabs = torch.rand(8, Cf, device=dev) + 0.5
+
+    def f1f(M=M, buf=buf, Cl=Cl, sc=sc, sh=sh, w1=w1, out=out128, H=H, acc_in=acc_in, acc_out=acc_out, tabs=tabs):
+        ext.conv_fwd_fused(buf[:, :Cl], acc_in, Cl - 32, sc, sh, tabs[0], tabs[1], tabs[2], tabs[3], tabs[4], tabs[5],
+                           tabs[6], float(M), 0.1, 1e-5, M, H, H, 1, w1, out, acc_out, a.bm, a.bf16)
+    cases.append((f"{blk}_fwd1x1_fused", 2.0 * M * Cl * 128, f1f))
+
+    def f2f(M=M, h=h, sc=sc, sh=sh, w2=w2, buf=buf, Cl=Cl, H=H, acc_in=acc_in, acc_out=acc_out, tabs=tabs):
+        ext.conv_fwd_fused(h, acc_in[:, :, :128], 0, sc, sh, tabs[0], tabs[1], tabs[2], tabs[3], tabs[4], tabs[5],
+                           tabs[6], float(M), 0.1, 1e-5, M, H, H, 9, w2, buf[:, Cl:Cl + 32], acc_out[:, :, :32],
+                           a.bm, a.bf16)
+    cases.append((f"{blk}_fwd3x3_fused", 2.0 * M * 1152 * 32, f2f))
+
     def f3(M=M, dbuf=dbuf, buf=buf, Cl=Cl, ones=ones, sc=sc, sh=sh, w2=w2, g2=g2, h=h, H=H):
         ext.conv_gemm(dbuf[:, Cl:Cl + 32], buf[:, Cl:Cl + 32], ones[:32], sc[:32], sh[:32], False, M, H, H, 9, True,
                       w2, True, g2, True, False, h, sc, sh, 2, a.bm, a.bf16)
@@ -103,7 +119,7 @@ for (blk, H, Cl, Cf) in [("b1", 56, 160, 256), ("b2", 28, 320, 512), ("b3", 14, 
     cases.append((f"{blk}_wgrad3x3", 2.0 * M * 1152 * 32, f6))
 
 for name, flops, fn in cases:
-    if a.only and a.only != name:
+    if a.only and a.only not in name:
         continue
     if a.sweep:
         if "wgrad" in name:

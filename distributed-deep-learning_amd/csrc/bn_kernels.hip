@@ -121,6 +121,36 @@ void launch_bn_prep(const float* partials, int G, int ldp, int new0, int n_new, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// fused-statistics bridge (FusedBn, conv_params.h): accumulators -> chan_mean / chan_var / chan_rstd for
+// the channels no fused consumer finalises (the last slice of a dense block, read by the next unit).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bn_acc_finalize_kernel(const long long* __restrict__ acc, int acc_ld, int c0,
+                                                              int n, double inv_count, float eps,
+                                                              float* __restrict__ chan_mean, float* __restrict__ chan_var,
+                                                              float* __restrict__ chan_rstd) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = c0 + i;
+  long long s1 = 0, s2 = 0;
+  for (int r = 0; r < kStatReplicas; ++r) {
+    s1 += acc[(long)(2 * r) * acc_ld + c];
+    s2 += acc[(long)(2 * r + 1) * acc_ld + c];
+  }
+  const double mean = (double)s1 * inv_count;
+  double var = (double)s2 * inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  chan_mean[c] = (float)mean;
+  chan_var[c] = (float)var;
+  chan_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+void launch_bn_acc_finalize(const long long* acc, int acc_ld, int c0, int n, double count, float eps, float* chan_mean,
+                            float* chan_var, float* chan_rstd, hipStream_t s) {
+  hipLaunchKernelGGL(bn_acc_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, acc, acc_ld, c0, n,
+                     1.0 / (count * kStatScale), eps, chan_mean, chan_var, chan_rstd);
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward prep.  partials = per-tile (sum g, sum g*x) of the masked upstream gradient g.
 //   dbeta += sum g ;  dgamma += rstd * (sum g*x - mean * sum g)
 //   a = sum g / M ; b = dgamma_batch / M ; BN backward is  dx = sc*g + k1*x + k2  with

@@ -116,6 +116,91 @@ at::Tensor conv_gemm(const at::Tensor& x0, const OptT& x1, const OptT& s0, const
   return stats;
 }
 
+// Forward conv of a dense layer with fused batch-norm statistics (training): the BN(+ReLU) prologue's
+// scale / shift come from the accumulators `acc_in` of the input channels (channels below `new0`: from the
+// mean / var / rstd tables an earlier call filled), the epilogue adds the output's column sums to `acc_out`.
+// Accumulators are [R, 2, ld] int64 views (sum, sum of squares; fixed point 2^28; R = kStatReplicas copies);
+// `acc_out` may be a column slice of a wider table.
+void check_acc(const at::Tensor& t, int64_t n, const char* name) {
+  TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kLong && t.dim() == 3 && t.size(0) == ddl::kStatReplicas &&
+                  t.size(1) == 2 && t.size(2) >= n && t.stride(2) == 1 && t.stride(0) == 2 * t.stride(1), name,
+              ": [", ddl::kStatReplicas, ", 2, >=", n, "] int64 view expected");
+}
+
+void conv_fwd_fused(const at::Tensor& x, const at::Tensor& acc_in, int64_t new0, const at::Tensor& gamma,
+                    const at::Tensor& beta, const OptT& run_mean, const OptT& run_var, at::Tensor scale_out,
+                    at::Tensor shift_out, at::Tensor mean, at::Tensor var, at::Tensor rstd, double count,
+                    double momentum, double eps, int64_t M, int64_t H, int64_t W, int64_t taps,
+                    const at::Tensor& weight, at::Tensor out, at::Tensor acc_out, int64_t force_bm, bool bf16) {
+  ddl::DeviceGuard guard(x.device());
+  const int64_t C = x.size(1), N = out.size(1);
+  TORCH_CHECK(taps == 1 || taps == 9, "taps must be 1 or 9");
+  TORCH_CHECK(M > 0 && M < (1LL << 31) && count > 0, "bad M / count");
+  TORCH_CHECK(C % 32 == 0 && C <= ddl::kMaxAffineC && N % 4 == 0, "conv_fwd_fused: C % 32 == 0, C <= 1024, N % 4 == 0");
+  TORCH_CHECK(new0 >= 0 && new0 <= C, "new0 out of range");
+  if (taps == 9) { TORCH_CHECK(H > 0 && W > 0 && M % (H * W) == 0, "M must be a whole number of HxW images"); }
+  ddl::ConvGemmParams p{};
+  p.a = make_src(x, c10::nullopt, c10::nullopt, c10::nullopt, c10::nullopt, true, M, C, "conv_fwd_fused input");
+  p.M = (int)M; p.C = (int)C; p.N = (int)N; p.H = (int)H; p.W = (int)W; p.taps = (int)taps;
+  TORCH_CHECK(weight.is_cuda() && weight.scalar_type() == at::kFloat && weight.dim() == 2 && weight.stride(1) == 1 &&
+                  weight.stride(0) % 4 == 0 && (reinterpret_cast<uintptr_t>(weight.data_ptr()) % 16) == 0 &&
+                  weight.size(0) == N && weight.size(1) == taps * C, "weight must be an aligned [N, taps*C] float32 tensor");
+  p.Wt = weight.data_ptr<float>(); p.ldb = (int)weight.stride(0);
+  check_rows(out, "out", M, N);
+  p.out = out.data_ptr<float>(); p.ldo = (int)out.stride(0);
+  check_acc(acc_in, C, "acc_in");
+  check_acc(acc_out, N, "acc_out");
+  p.bn.acc = reinterpret_cast<const long long*>(acc_in.data_ptr<int64_t>());
+  p.bn.acc_ld = (int)acc_in.stride(1);
+  p.bn.new0 = (int)new0;
+  p.bn.acc_out = reinterpret_cast<long long*>(acc_out.data_ptr<int64_t>());
+  p.bn.acc_out_ld = (int)acc_out.stride(1);
+  p.bn.gamma = vec_ptr(gamma, "gamma", C);
+  p.bn.beta = vec_ptr(beta, "beta", C);
+  auto out_vec = [&](const at::Tensor& t, const char* name) {
+    TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kFloat && t.dim() == 1 && t.stride(0) == 1 && t.size(0) >= C, name,
+                ": contiguous float32 vector of >= ", C, " expected");
+    return t.data_ptr<float>();
+  };
+  p.bn.scale_out = out_vec(scale_out, "scale_out");
+  p.bn.shift_out = out_vec(shift_out, "shift_out");
+  p.bn.mean = out_vec(mean, "mean");
+  p.bn.var = out_vec(var, "var");
+  p.bn.rstd = out_vec(rstd, "rstd");
+  if (run_mean.has_value()) {
+    TORCH_CHECK(run_var.has_value(), "run_mean and run_var come together");
+    p.bn.run_mean = out_vec(*run_mean, "run_mean");
+    p.bn.run_var = out_vec(*run_var, "run_var");
+  }
+  p.bn.inv_count = 1.0 / (count * ddl::kStatScale);
+  p.bn.unbias = count > 1.0 ? (float)(count / (count - 1.0)) : 1.f;
+  p.bn.momentum = (float)momentum;
+  p.bn.eps = (float)eps;
+  p.stats = 3;
+  p.kind = 0;
+  p.bf16 = bf16 ? 1 : 0;
+  const int64_t cch = C / 32;
+  TORCH_CHECK(taps * cch <= 320, "conv_fwd_fused: K too large for the sub-slab index arithmetic");
+  p.inv_cc = (int)((65536 + cch - 1) / cch);
+  const int64_t wb = ((N - 1) * (int64_t)p.ldb + taps * C) * 4, ob = ((M - 1) * (int64_t)p.ldo + N) * 4;
+  TORCH_CHECK(wb < (1LL << 31) && ob < (1LL << 31), "conv_fwd_fused: views must span < 2 GiB");
+  p.wbytes = (unsigned)wb; p.obytes = (unsigned)ob;
+  ddl::launch_conv_gemm(p, (int)force_bm, cur_stream());
+}
+
+void bn_acc_finalize(const at::Tensor& acc, int64_t c0, int64_t n, double count, double eps, at::Tensor chan_mean,
+                     at::Tensor chan_var, at::Tensor chan_rstd) {
+  ddl::DeviceGuard guard(acc.device());
+  check_acc(acc, c0 + n, "acc");
+  TORCH_CHECK(c0 >= 0 && n > 0 && count > 0, "bn_acc_finalize: bad range / count");
+  for (const at::Tensor* t : std::initializer_list<const at::Tensor*>{&chan_mean, &chan_var, &chan_rstd})
+    TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kFloat && t->is_contiguous() && t->numel() >= c0 + n,
+                "channel stat table too small");
+  ddl::launch_bn_acc_finalize(reinterpret_cast<const long long*>(acc.data_ptr<int64_t>()), (int)acc.stride(1), (int)c0,
+                              (int)n, count, (float)eps, chan_mean.data_ptr<float>(), chan_var.data_ptr<float>(),
+                              chan_rstd.data_ptr<float>(), cur_stream());
+}
+
 // dW[N, taps*C] += dO^T * rows(A)
 void conv_wgrad(const at::Tensor& d0, const OptT& d1, const OptT& ds0, const OptT& ds1, const OptT& ds2,
                 const at::Tensor& a0, const OptT& as0, const OptT& as2, bool a_relu, int64_t M, int64_t H,
@@ -247,6 +332,9 @@ void register_conv_ops(pybind11::module_& m) {
         pybind11::arg("flip"), pybind11::arg("weight"), pybind11::arg("b_kmajor"), pybind11::arg("out"),
         pybind11::arg("ep_mask"), pybind11::arg("ep_accum"), pybind11::arg("aux"), pybind11::arg("e0"),
         pybind11::arg("e1"), pybind11::arg("stats_mode"), pybind11::arg("force_bm"), pybind11::arg("bf16") = false);
+  m.def("conv_fwd_fused", &conv_fwd_fused, "forward conv with fused batch-norm statistics (accumulator in / out)");
+  m.attr("STAT_REPLICAS") = pybind11::int_(ddl::kStatReplicas);
+  m.def("bn_acc_finalize", &bn_acc_finalize, "accumulators -> channel mean / var / rstd");
   m.def("conv_wgrad", &conv_wgrad, "conv weight gradient (split-M slabs + deterministic reduce)");
   m.def("bn_prep", &bn_prep, "finalize channel statistics, derive BN scale/shift, update running stats");
   m.def("bn_bwd_prep", &bn_bwd_prep, "BN backward per-channel coefficients, dgamma/dbeta");

@@ -71,10 +71,16 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
   static_assert(TM >= 1 && TN >= 1, "bad wave layout");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                        // [NBUF][BM][LDA]
-  float* Bs = smem + NBUF * BM * LDA;      // [NBUF][B_ELEMS]
-  __bf16* Ah = reinterpret_cast<__bf16*>(smem);       // BF: [NBUF][BM][LDH]
-  __bf16* Bh = Ah + NBUF * BM * LDH;                  //     [NBUF][BN][LDH]
+  // forward kind with a BN prologue: scale / shift of all C channels live in LDS ahead of the staging
+  // buffers (copied from the tables, or derived from the fused-statistics accumulators)
+  const bool affine = p.a.s0 != nullptr || (KIND == 0 && p.bn.acc != nullptr);
+  const int soff = (KIND == 0 && affine) ? 2 * p.C : 0;
+  float* scs = smem;                       // [C] scale, [C] shift
+  float* shs = smem + p.C;
+  float* As = smem + soff;                 // [NBUF][BM][LDA]
+  float* Bs = As + NBUF * BM * LDA;        // [NBUF][B_ELEMS]
+  __bf16* Ah = reinterpret_cast<__bf16*>(smem + soff);   // BF: [NBUF][BM][LDH]
+  __bf16* Bh = Ah + NBUF * BM * LDH;                     //     [NBUF][BN][LDH]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int ks = wid / (WM * WN);
@@ -98,7 +104,6 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
   const rsrc_t rA0 = make_rsrc(p.a.X0, p.a.bytes0);
   const rsrc_t rA1 = make_rsrc(TWO ? p.a.X1 : p.a.X0, TWO ? p.a.bytes1 : p.a.bytes0);
   const rsrc_t rW = make_rsrc(p.Wt, p.wbytes);
-  const bool affine = p.a.s0 != nullptr;
 
   // ---- per-thread bookkeeping -----------------------------------------------------------------
   const int aq = tid % Q;                  // this thread's float4 column inside a slab row
@@ -137,6 +142,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
   struct Stage {
     f32x4 a_v0[PA], a_v1[TWO ? PA : 1];
     f32x4 a_s0, a_s1, a_s2;
+    int a_c;
     unsigned a_mask;
     f32x4 b_reg[PB];
   };
@@ -164,7 +170,8 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
       const unsigned d0 = (unsigned)((pix * p.a.ld0 + c) * 4);
       const unsigned d1 = TWO ? (unsigned)((pix * p.a.ld1 + c) * 4) : 0u;
       S.a_s0 = zero4; S.a_s1 = zero4; S.a_s2 = zero4;
-      if (affine) {                        // c < C always (even for idx >= NS the loads stay in range)
+      S.a_c = c;                           // forward kind: scale / shift come from LDS at store time
+      if (KIND != 0 && affine) {           // c < C always (even for idx >= NS the loads stay in range)
         S.a_s0 = ld4(p.a.s0 + c);
         S.a_s2 = ld4(p.a.s2 + c);
         if (TWO) S.a_s1 = ld4(p.a.s1 + c);
@@ -205,7 +212,8 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
     for (int i = 0; i < PA; ++i) {
       f32x4 v = S.a_v0[i];
       if (affine) {          // deferred prologue: BN affine (+ second source) + ReLU, zero where invalid
-        v = S.a_s0 * v + S.a_s2;
+        if (KIND == 0) v = ld4(scs + S.a_c) * v + ld4(shs + S.a_c);
+        else v = S.a_s0 * v + S.a_s2;
         if (TWO) v += S.a_s1 * S.a_v1[i];
         if (p.a.relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -293,11 +301,55 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
     }
   };
 
+  // ---- forward BN prologue tables -> LDS (runs while the first slab's global loads are in flight) ----
+  auto bn_tables = [&]() {
+    if (KIND != 0 || !affine) return;
+    if (p.bn.acc == nullptr) {
+      for (int c = tid; c < p.C; c += NT) { scs[c] = p.a.s0[c]; shs[c] = p.a.s2[c]; }
+      return;
+    }
+    const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
+    for (int c = tid; c < p.C; c += NT) {
+      float meanf, varf, rstd;
+      if (c < p.bn.new0) {                 // finalised by an earlier consumer
+        meanf = p.bn.mean[c]; varf = p.bn.var[c]; rstd = p.bn.rstd[c];
+      } else {
+        long long s1 = 0, s2 = 0;
+#pragma unroll
+        for (int r = 0; r < kStatReplicas; ++r) {
+          s1 += p.bn.acc[(long)(2 * r) * p.bn.acc_ld + c];
+          s2 += p.bn.acc[(long)(2 * r + 1) * p.bn.acc_ld + c];
+        }
+        const double mean = (double)s1 * p.bn.inv_count;
+        double var = (double)s2 * p.bn.inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        meanf = (float)mean; varf = (float)var;
+        rstd = __frsqrt_rn(varf + p.bn.eps);                     // + one Newton step: full fp32 accuracy
+        rstd = rstd * (1.5f - 0.5f * (varf + p.bn.eps) * rstd * rstd);
+        if (writer) { p.bn.mean[c] = meanf; p.bn.var[c] = varf; p.bn.rstd[c] = rstd; }
+      }
+      const float sc = p.bn.gamma[c] * rstd;
+      const float sh = p.bn.beta[c] - meanf * sc;
+      scs[c] = sc;
+      shs[c] = sh;
+      if (writer) {
+        p.bn.scale_out[c] = sc;
+        p.bn.shift_out[c] = sh;
+        if (p.bn.run_mean != nullptr) {
+          p.bn.run_mean[c] = (1.f - p.bn.momentum) * p.bn.run_mean[c] + p.bn.momentum * meanf;
+          p.bn.run_var[c] = (1.f - p.bn.momentum) * p.bn.run_var[c] + p.bn.momentum * varf * p.bn.unbias;
+        }
+      }
+    }
+  };
+
   // ---- main loop: register-staged; NBUF = 2: one barrier per slab, NBUF = 1: half the LDS
   // (more workgroups per CU hide the extra barrier and every other latency) -------------------
   if (PF == 1) {
     Stage S;
     load_slab(0, S);
+    bn_tables();
+    if (KIND == 0) __syncthreads();
     store_slab(0, S);
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
@@ -315,6 +367,8 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
     Stage S0, S1;
     load_slab(0, S0);
     if (KT > 1) load_slab(1, S1);
+    bn_tables();
+    if (KIND == 0) __syncthreads();
     store_slab(0, S0);
     __syncthreads();
     for (int kt = 0; kt < KT; kt += 2) {
@@ -435,7 +489,12 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
         float s = 0.f;
 #pragma unroll
         for (int g = 0; g < RG; ++g) s += red[(which * RG + g) * BN + cc];
-        p.stats_out[((long)tile_x * 2 + which) * p.N + n0 + cc] = s;
+        if (KIND == 0 && p.stats == 3) {   // fused statistics: fixed-point integer atomics (order-independent)
+          __hip_atomic_fetch_add(p.bn.acc_out + (long)(2 * (tile_x & (kStatReplicas - 1)) + which) * p.bn.acc_out_ld + n0 + cc,
+                                 __double2ll_rn((double)s * kStatScale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          p.stats_out[((long)tile_x * 2 + which) * p.N + n0 + cc] = s;
+        }
       }
     }
   }
@@ -452,11 +511,15 @@ void launch_inst(const ConvGemmParams& p, hipStream_t s) {
   constexpr size_t epi = (size_t)WM * WN * 32 * 36 * sizeof(float);      // epilogue transposition images
   constexpr size_t sta = (size_t)2 * WM * 8 * BN * sizeof(float);        // statistics combine
   constexpr size_t m1 = stage > red ? stage : red, m2 = epi > sta ? epi : sta;
-  constexpr size_t lds = m1 > m2 ? m1 : m2;
+  constexpr size_t lds_max = (m1 > m2 ? m1 : m2) + (KIND == 0 ? kMaxAffineC * 2 * sizeof(float) : 0);
+  // forward kind with a BN prologue: scale / shift image of the C input channels ahead of the staging buffers
+  const size_t tables = (KIND == 0 && (p.a.s0 != nullptr || p.bn.acc != nullptr)) ? (size_t)p.C * 2 * sizeof(float) : 0;
+  const size_t m1t = (stage + tables) > red ? (stage + tables) : red;
+  const size_t lds = m1t > m2 ? m1t : m2;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, KS, NBUF, PF, KIND, BF>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     attr_set = true;
   }
   dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.N + BN - 1) / BN));

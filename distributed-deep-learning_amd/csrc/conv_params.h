@@ -24,9 +24,41 @@ struct RowSrc {
   unsigned bytes1;
 };
 
+// Fused batch-norm statistics (forward, training).  The producing conv adds its per-tile column sums
+// to 64-bit fixed-point accumulators (integer atomics are order-independent, so the result stays
+// deterministic) and the consuming conv derives scale / shift from them in its own prologue: no
+// bn_prep launch sits between the two on the critical path.  Workgroup (0,0) of the consumer also
+// writes the tables the backward pass reads and updates the running statistics.
+//   * kStatReplicas accumulator copies (row tile index mod 8) keep the atomics of a 700-tile grid from
+//     serialising on one cache line; the consumer adds the copies (exact integer sums).
+//   * channels below `new0` were finalised by an earlier consumer (dense block: every layer's 1x1 conv
+//     sees the whole prefix but only the last 32 channels are new): they come from the float tables.
+constexpr double kStatScale = 268435456.0;      // 2^28: fixed-point scale of the accumulators
+constexpr int kStatReplicas = 8;
+constexpr int kMaxAffineC = 1024;               // forward BN prologue: scale / shift of <= 1024 channels staged in LDS
+struct FusedBn {
+  const long long* acc;     // in: [R][2][acc_ld] sum / sum of squares of the row source's channels (nullptr: off)
+  int acc_ld;
+  int new0;                 // channels [new0, C) come from `acc`, channels [0, new0) from mean/var/rstd tables
+  const float* gamma;
+  const float* beta;
+  float* run_mean;          // momentum update (may be nullptr)
+  float* run_var;
+  float* scale_out;         // gamma*rstd, beta - mean*scale: saved for backward
+  float* shift_out;
+  float* mean;              // channel statistics tables: read below new0, written from new0 on
+  float* var;
+  float* rstd;
+  double inv_count;         // 1 / (pixels * kStatScale)
+  float unbias, momentum, eps;
+  long long* acc_out;       // out (stats == 3): accumulators of the produced channels, [R][2][acc_out_ld]
+  int acc_out_ld;
+};
+
 // out[M x N] (op)= rows(A)[M x taps*C] * W
 struct ConvGemmParams {
   RowSrc a;
+  FusedBn bn;
   int M, C, N;        // pixels, channels per tap of the row source (GEMM K = taps*C), output channels
   int H, W;           // spatial size (3x3 taps only)
   int taps;           // 1 or 9 (3x3, stride 1, pad 1)
@@ -45,7 +77,7 @@ struct ConvGemmParams {
   int ldaux;
   const float* e0;
   const float* e1;
-  int stats;          // 0 none; 1: per-column sum(v), sum(v*v); 2: sum(g), sum(g*aux)
+  int stats;          // 0 none; 1: per-column sum(v), sum(v*v); 2: sum(g), sum(g*aux); 3: as 1 into bn.acc_out
   float* stats_out;   // [gridDim.x][2][N]
   // derived on the host (conv_bindings.cpp: finish_params)
   int kind;           // 0 FWD, 1 TDGRAD, 2 DGRAD3, 3 DGRAD1 (see conv_gemm.hip)

@@ -40,6 +40,8 @@ void launch_bn_prep(const float* partials, int G, int ldp, int new0, int n_new, 
 void launch_bn_bwd_prep(const float* partials, int G, int ldp, double count, const float* chan_mean,
                         const float* chan_rstd, const float* scale, float* dgamma, float* dbeta, float* k0,
                         float* k1, float* k2, int C, int mode, hipStream_t s);
+void launch_bn_acc_finalize(const long long* acc, int acc_ld, int c0, int n, double count, float eps, float* chan_mean,
+                            float* chan_var, float* chan_rstd, hipStream_t s);
 int rows_op_grid(long M, int C);
 int launch_rows_op(int mode, long M, int C, const float* in, int ldi, const float* x, int ldx,
                    const float* sc, const float* sh, float* out, int ldo, int H, int W, float* stats,
