@@ -30,7 +30,7 @@ const float* vec_ptr(const OptT& v, const char* name, int64_t n) {
 }
 
 ddl::RowSrc make_src(const at::Tensor& x0, const OptT& x1, const OptT& s0, const OptT& s1, const OptT& s2,
-                     bool relu, int64_t rows, int64_t ch, const char* name) {
+                     bool relu, int64_t rows, int64_t ch, const char* name, bool fused_affine = false) {
   ddl::RowSrc r{};
   check_rows(x0, name, rows, ch);
   r.X0 = x0.data_ptr<float>();
@@ -43,7 +43,8 @@ ddl::RowSrc make_src(const at::Tensor& x0, const OptT& x1, const OptT& s0, const
     r.X1 = x1->data_ptr<float>();
     r.ld1 = (int)x1->stride(0);
     r.s1 = vec_ptr(s1, "s1", ch);
-    TORCH_CHECK(r.s0 != nullptr && r.s1 != nullptr, name, ": a second source needs s0, s1, s2");
+    TORCH_CHECK(fused_affine ? (r.s0 == nullptr && r.s1 == nullptr) : (r.s0 != nullptr && r.s1 != nullptr), name,
+                ": a second source needs s0, s1, s2 (or fused coefficients instead of them)");
   }
   r.relu = relu ? 1 : 0;
   // extents for the buffer descriptors (32-bit offsets, hardware bounds check)
@@ -55,11 +56,43 @@ ddl::RowSrc make_src(const at::Tensor& x0, const OptT& x1, const OptT& s0, const
   return r;
 }
 
+void check_acc(const at::Tensor& t, int64_t n, const char* name) {
+  TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kLong && t.dim() == 3 && t.size(0) == ddl::kStatReplicas &&
+                  t.size(1) == 2 && t.size(2) >= n && t.stride(2) == 1 && t.stride(0) == 2 * t.stride(1), name,
+              ": [", ddl::kStatReplicas, ", 2, >=", n, "] int64 view expected");
+}
+
+float* fvec(const at::Tensor& t, int64_t n, const char* name) {
+  TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kFloat && t.dim() == 1 && t.stride(0) == 1 && t.size(0) >= n, name,
+              ": contiguous float32 vector of >= ", n, " expected");
+  return t.data_ptr<float>();
+}
+
+// fused BN-backward coefficients (FusedK): accumulators + the BN's forward statistics
+ddl::FusedK make_fk(const OptT& acc, const OptT& mean, const OptT& rstd, const OptT& scale, const OptT& dgamma,
+                    const OptT& dbeta, double count, int64_t n) {
+  ddl::FusedK f{};
+  if (!acc.has_value()) return f;
+  TORCH_CHECK(mean.has_value() && rstd.has_value() && scale.has_value() && count > 0, "fused k: mean, rstd, scale, count");
+  check_acc(*acc, n, "k_acc");
+  f.acc = reinterpret_cast<const long long*>(acc->data_ptr<int64_t>());
+  f.acc_ld = (int)acc->stride(1);
+  f.mean = fvec(*mean, n, "k_mean"); f.rstd = fvec(*rstd, n, "k_rstd"); f.scale = fvec(*scale, n, "k_scale");
+  f.inv_count = 1.0 / count;
+  if (dgamma.has_value()) {
+    TORCH_CHECK(dbeta.has_value(), "dgamma and dbeta come together");
+    f.dgamma = fvec(*dgamma, n, "dgamma"); f.dbeta = fvec(*dbeta, n, "dbeta");
+  }
+  return f;
+}
+
 // out (op)= prologue(x0, x1) (*) weight.  Returns the per-tile statistics table [G,2,N] (or empty).
 at::Tensor conv_gemm(const at::Tensor& x0, const OptT& x1, const OptT& s0, const OptT& s1, const OptT& s2,
                      bool relu, int64_t M, int64_t H, int64_t W, int64_t taps, bool flip,
                      const at::Tensor& weight, bool b_kmajor, at::Tensor out, bool ep_mask, bool ep_accum,
-                     const OptT& aux, const OptT& e0, const OptT& e1, int64_t stats_mode, int64_t force_bm, bool bf16) {
+                     const OptT& aux, const OptT& e0, const OptT& e1, int64_t stats_mode, int64_t force_bm, bool bf16,
+                     const OptT& acc_out, const OptT& k_acc, const OptT& k_mean, const OptT& k_rstd,
+                     const OptT& k_scale, const OptT& k_dgamma, const OptT& k_dbeta, double k_count) {
   ddl::DeviceGuard guard(x0.device());
   const int64_t C = x0.size(1), N = out.size(1);
   TORCH_CHECK(taps == 1 || taps == 9, "taps must be 1 or 9");
@@ -69,7 +102,8 @@ at::Tensor conv_gemm(const at::Tensor& x0, const OptT& x1, const OptT& s0, const
     TORCH_CHECK(H > 0 && W > 0 && M % (H * W) == 0, "M must be a whole number of HxW images");
   }
   ddl::ConvGemmParams p{};
-  p.a = make_src(x0, x1, s0, s1, s2, relu, M, C, "conv_gemm input");
+  p.a = make_src(x0, x1, s0, s1, s2, relu, M, C, "conv_gemm input", k_acc.has_value());
+  p.fk = make_fk(k_acc, k_mean, k_rstd, k_scale, k_dgamma, k_dbeta, k_count, C);
   p.M = (int)M; p.C = (int)C; p.N = (int)N; p.H = (int)H; p.W = (int)W; p.taps = (int)taps; p.flip = flip ? 1 : 0;
   TORCH_CHECK(weight.is_cuda() && weight.scalar_type() == at::kFloat && weight.dim() == 2 &&
                   weight.stride(1) == 1 && weight.stride(0) % 4 == 0 &&
@@ -106,8 +140,16 @@ at::Tensor conv_gemm(const at::Tensor& x0, const OptT& x1, const OptT& s0, const
   const int64_t xb = p.aux ? ((M - 1) * (int64_t)p.ldaux + N) * 4 : 0;
   TORCH_CHECK(wb < (1LL << 31) && ob < (1LL << 31) && xb < (1LL << 31), "conv_gemm: views must span < 2 GiB");
   p.wbytes = (unsigned)wb; p.obytes = (unsigned)ob; p.auxbytes = (unsigned)xb;
+  if (p.fk.acc != nullptr) { TORCH_CHECK(p.kind == 3 && C <= ddl::kMaxAffineC, "fused k: 1x1 data gradient only"); }
+  if (p.kind == 3) { TORCH_CHECK(C <= ddl::kMaxAffineC, "conv_gemm: dgrad1x1 stages its coefficients for <= 1024 channels"); }
+  if (p.kind == 0 && p.a.s0 != nullptr) { TORCH_CHECK(C <= ddl::kMaxAffineC, "conv_gemm: BN prologue for <= 1024 channels"); }
   at::Tensor stats;
-  if (stats_mode) {
+  if (acc_out.has_value()) {            // statistics into fixed-point accumulators instead of a per-tile table
+    TORCH_CHECK(stats_mode != 0 && (p.kind == 0 || p.kind == 2), "acc_out: forward / 3x3 data-gradient statistics only");
+    check_acc(*acc_out, N, "acc_out");
+    p.bn.acc_out = reinterpret_cast<long long*>(acc_out->data_ptr<int64_t>());
+    p.bn.acc_out_ld = (int)acc_out->stride(1);
+  } else if (stats_mode) {
     const int G = ddl::conv_gemm_grid_x((int)M, (int)N, (int)force_bm);
     stats = at::empty({G, 2, N}, x0.options());
     p.stats_out = stats.data_ptr<float>();
@@ -121,12 +163,6 @@ at::Tensor conv_gemm(const at::Tensor& x0, const OptT& x1, const OptT& s0, const
 // mean / var / rstd tables an earlier call filled), the epilogue adds the output's column sums to `acc_out`.
 // Accumulators are [R, 2, ld] int64 views (sum, sum of squares; fixed point 2^28; R = kStatReplicas copies);
 // `acc_out` may be a column slice of a wider table.
-void check_acc(const at::Tensor& t, int64_t n, const char* name) {
-  TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kLong && t.dim() == 3 && t.size(0) == ddl::kStatReplicas &&
-                  t.size(1) == 2 && t.size(2) >= n && t.stride(2) == 1 && t.stride(0) == 2 * t.stride(1), name,
-              ": [", ddl::kStatReplicas, ", 2, >=", n, "] int64 view expected");
-}
-
 void conv_fwd_fused(const at::Tensor& x, const at::Tensor& acc_in, int64_t new0, const at::Tensor& gamma,
                     const at::Tensor& beta, const OptT& run_mean, const OptT& run_var, at::Tensor scale_out,
                     at::Tensor shift_out, at::Tensor mean, at::Tensor var, at::Tensor rstd, double count,
@@ -204,13 +240,16 @@ void bn_acc_finalize(const at::Tensor& acc, int64_t c0, int64_t n, double count,
 // dW[N, taps*C] += dO^T * rows(A)
 void conv_wgrad(const at::Tensor& d0, const OptT& d1, const OptT& ds0, const OptT& ds1, const OptT& ds2,
                 const at::Tensor& a0, const OptT& as0, const OptT& as2, bool a_relu, int64_t M, int64_t H,
-                int64_t W, int64_t taps, at::Tensor dW, int64_t min_rows) {
+                int64_t W, int64_t taps, at::Tensor dW, int64_t min_rows, const OptT& k_acc, const OptT& k_mean,
+                const OptT& k_rstd, const OptT& k_scale, double k_count) {
   ddl::DeviceGuard guard(d0.device());
   const int64_t N = d0.size(1), C = a0.size(1);
   TORCH_CHECK(taps == 1 || taps == 9, "taps must be 1 or 9");
   TORCH_CHECK(M > 0 && M < (1LL << 31), "bad M");
   ddl::WgradParams p{};
-  p.d = make_src(d0, d1, ds0, ds1, ds2, false, M, N, "wgrad dO");
+  p.d = make_src(d0, d1, ds0, ds1, ds2, false, M, N, "wgrad dO", k_acc.has_value());
+  p.fk = make_fk(k_acc, k_mean, k_rstd, k_scale, c10::nullopt, c10::nullopt, k_count, N);
+  if (p.fk.acc != nullptr) { TORCH_CHECK(taps == 1 && d1.has_value(), "fused k: 1x1 weight gradient with two dO sources"); }
   p.a = make_src(a0, c10::nullopt, as0, c10::nullopt, as2, a_relu, M, C, "wgrad activation");
   p.M = (int)M; p.C = (int)C; p.N = (int)N; p.H = (int)H; p.W = (int)W; p.taps = (int)taps;
   if (taps == 9) {
@@ -331,11 +370,20 @@ void register_conv_ops(pybind11::module_& m) {
         pybind11::arg("relu"), pybind11::arg("M"), pybind11::arg("H"), pybind11::arg("W"), pybind11::arg("taps"),
         pybind11::arg("flip"), pybind11::arg("weight"), pybind11::arg("b_kmajor"), pybind11::arg("out"),
         pybind11::arg("ep_mask"), pybind11::arg("ep_accum"), pybind11::arg("aux"), pybind11::arg("e0"),
-        pybind11::arg("e1"), pybind11::arg("stats_mode"), pybind11::arg("force_bm"), pybind11::arg("bf16") = false);
+        pybind11::arg("e1"), pybind11::arg("stats_mode"), pybind11::arg("force_bm"), pybind11::arg("bf16") = false,
+        pybind11::arg("acc_out") = c10::nullopt, pybind11::arg("k_acc") = c10::nullopt,
+        pybind11::arg("k_mean") = c10::nullopt, pybind11::arg("k_rstd") = c10::nullopt,
+        pybind11::arg("k_scale") = c10::nullopt, pybind11::arg("k_dgamma") = c10::nullopt,
+        pybind11::arg("k_dbeta") = c10::nullopt, pybind11::arg("k_count") = 0.0);
   m.def("conv_fwd_fused", &conv_fwd_fused, "forward conv with fused batch-norm statistics (accumulator in / out)");
   m.attr("STAT_REPLICAS") = pybind11::int_(ddl::kStatReplicas);
   m.def("bn_acc_finalize", &bn_acc_finalize, "accumulators -> channel mean / var / rstd");
-  m.def("conv_wgrad", &conv_wgrad, "conv weight gradient (split-M slabs + deterministic reduce)");
+  m.def("conv_wgrad", &conv_wgrad, "conv weight gradient (split-M slabs + deterministic reduce)",
+        pybind11::arg("d0"), pybind11::arg("d1"), pybind11::arg("ds0"), pybind11::arg("ds1"), pybind11::arg("ds2"),
+        pybind11::arg("a0"), pybind11::arg("as0"), pybind11::arg("as2"), pybind11::arg("a_relu"), pybind11::arg("M"),
+        pybind11::arg("H"), pybind11::arg("W"), pybind11::arg("taps"), pybind11::arg("dW"), pybind11::arg("min_rows"),
+        pybind11::arg("k_acc") = c10::nullopt, pybind11::arg("k_mean") = c10::nullopt,
+        pybind11::arg("k_rstd") = c10::nullopt, pybind11::arg("k_scale") = c10::nullopt, pybind11::arg("k_count") = 0.0);
   m.def("bn_prep", &bn_prep, "finalize channel statistics, derive BN scale/shift, update running stats");
   m.def("bn_bwd_prep", &bn_bwd_prep, "BN backward per-channel coefficients, dgamma/dbeta");
   m.def("rows_op", &rows_op, "pixel glue ops (copy+stats, pool fwd/bwd, gap bwd, deferred-term apply)");

@@ -73,10 +73,12 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // forward kind with a BN prologue: scale / shift of all C channels live in LDS ahead of the staging
   // buffers (copied from the tables, or derived from the fused-statistics accumulators)
-  const bool affine = p.a.s0 != nullptr || (KIND == 0 && p.bn.acc != nullptr);
-  const int soff = (KIND == 0 && affine) ? 2 * p.C : 0;
-  float* scs = smem;                       // [C] scale, [C] shift
+  const bool affine = p.a.s0 != nullptr || (KIND == 0 && p.bn.acc != nullptr) || (KIND == 3 && p.fk.acc != nullptr);
+  constexpr bool LDS_TABLES = KIND == 0 || KIND == 3;     // per-channel prologue vectors staged in LDS
+  const int soff = (LDS_TABLES && affine) ? (KIND == 0 ? 2 : 3) * p.C : 0;
+  float* scs = smem;                       // KIND 0: [C] scale, [C] shift;  KIND 3: [C] k0, [C] k2, [C] k1
   float* shs = smem + p.C;
+  float* k1s = smem + 2 * p.C;
   float* As = smem + soff;                 // [NBUF][BM][LDA]
   float* Bs = As + NBUF * BM * LDA;        // [NBUF][B_ELEMS]
   __bf16* Ah = reinterpret_cast<__bf16*>(smem + soff);   // BF: [NBUF][BM][LDH]
@@ -171,7 +173,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
       const unsigned d1 = TWO ? (unsigned)((pix * p.a.ld1 + c) * 4) : 0u;
       S.a_s0 = zero4; S.a_s1 = zero4; S.a_s2 = zero4;
       S.a_c = c;                           // forward kind: scale / shift come from LDS at store time
-      if (KIND != 0 && affine) {           // c < C always (even for idx >= NS the loads stay in range)
+      if (!LDS_TABLES && affine) {         // c < C always (even for idx >= NS the loads stay in range)
         S.a_s0 = ld4(p.a.s0 + c);
         S.a_s2 = ld4(p.a.s2 + c);
         if (TWO) S.a_s1 = ld4(p.a.s1 + c);
@@ -212,9 +214,9 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
     for (int i = 0; i < PA; ++i) {
       f32x4 v = S.a_v0[i];
       if (affine) {          // deferred prologue: BN affine (+ second source) + ReLU, zero where invalid
-        if (KIND == 0) v = ld4(scs + S.a_c) * v + ld4(shs + S.a_c);
+        if (LDS_TABLES) v = ld4(scs + S.a_c) * v + ld4(shs + S.a_c);
         else v = S.a_s0 * v + S.a_s2;
-        if (TWO) v += S.a_s1 * S.a_v1[i];
+        if (TWO) v += (KIND == 3 ? ld4(k1s + S.a_c) : S.a_s1) * S.a_v1[i];
         if (p.a.relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
@@ -303,7 +305,22 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
 
   // ---- forward BN prologue tables -> LDS (runs while the first slab's global loads are in flight) ----
   auto bn_tables = [&]() {
-    if (KIND != 0 || !affine) return;
+    if (!LDS_TABLES || !affine) return;
+    if (KIND == 3) {
+      const bool writer = blockIdx.x == 0 && blockIdx.y == 0 && p.fk.dgamma != nullptr;
+      for (int c = tid; c < p.C; c += NT) {
+        float k0, k1, k2;
+        if (p.fk.acc != nullptr) {
+          float dg, db;
+          fused_k(p.fk, c, kStatReplicas, 1.0 / kStatScale, k0, k1, k2, dg, db);
+          if (writer) { p.fk.dgamma[c] += dg; p.fk.dbeta[c] += db; }
+        } else {
+          k0 = p.a.s0[c]; k1 = p.a.s1[c]; k2 = p.a.s2[c];
+        }
+        scs[c] = k0; shs[c] = k2; k1s[c] = k1;
+      }
+      return;
+    }
     if (p.bn.acc == nullptr) {
       for (int c = tid; c < p.C; c += NT) { scs[c] = p.a.s0[c]; shs[c] = p.a.s2[c]; }
       return;
@@ -349,7 +366,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
     Stage S;
     load_slab(0, S);
     bn_tables();
-    if (KIND == 0) __syncthreads();
+    if (LDS_TABLES) __syncthreads();
     store_slab(0, S);
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
@@ -368,7 +385,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
     load_slab(0, S0);
     if (KT > 1) load_slab(1, S1);
     bn_tables();
-    if (KIND == 0) __syncthreads();
+    if (LDS_TABLES) __syncthreads();
     store_slab(0, S0);
     __syncthreads();
     for (int kt = 0; kt < KT; kt += 2) {
@@ -489,7 +506,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
         float s = 0.f;
 #pragma unroll
         for (int g = 0; g < RG; ++g) s += red[(which * RG + g) * BN + cc];
-        if (KIND == 0 && p.stats == 3) {   // fused statistics: fixed-point integer atomics (order-independent)
+        if ((KIND == 0 || KIND == 2) && p.bn.acc_out != nullptr) {   // fused statistics: fixed-point integer atomics
           __hip_atomic_fetch_add(p.bn.acc_out + (long)(2 * (tile_x & (kStatReplicas - 1)) + which) * p.bn.acc_out_ld + n0 + cc,
                                  __double2ll_rn((double)s * kStatScale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
@@ -511,9 +528,11 @@ void launch_inst(const ConvGemmParams& p, hipStream_t s) {
   constexpr size_t epi = (size_t)WM * WN * 32 * 36 * sizeof(float);      // epilogue transposition images
   constexpr size_t sta = (size_t)2 * WM * 8 * BN * sizeof(float);        // statistics combine
   constexpr size_t m1 = stage > red ? stage : red, m2 = epi > sta ? epi : sta;
-  constexpr size_t lds_max = (m1 > m2 ? m1 : m2) + (KIND == 0 ? kMaxAffineC * 2 * sizeof(float) : 0);
-  // forward kind with a BN prologue: scale / shift image of the C input channels ahead of the staging buffers
-  const size_t tables = (KIND == 0 && (p.a.s0 != nullptr || p.bn.acc != nullptr)) ? (size_t)p.C * 2 * sizeof(float) : 0;
+  constexpr size_t lds_max = (m1 > m2 ? m1 : m2) + ((KIND == 0 || KIND == 3) ? kMaxAffineC * 3 * sizeof(float) : 0);
+  // kinds 0 / 3: per-channel prologue vectors of the C input channels ahead of the staging buffers
+  const bool has_tables = (KIND == 0 && (p.a.s0 != nullptr || p.bn.acc != nullptr)) ||
+                          (KIND == 3 && (p.a.s0 != nullptr || p.fk.acc != nullptr));
+  const size_t tables = has_tables ? (size_t)p.C * (KIND == 0 ? 2 : 3) * sizeof(float) : 0;
   const size_t m1t = (stage + tables) > red ? (stage + tables) : red;
   const size_t lds = m1t > m2 ? m1t : m2;
   static bool attr_set = false;

@@ -55,10 +55,26 @@ struct FusedBn {
   int acc_out_ld;
 };
 
+// Fused BN-backward coefficients.  BN backward is dh = k0*g + k1*h + k2 with per-channel k's that depend
+// on (sum g, sum g*h) over all pixels.  The data-gradient kernel that produces g adds those sums to
+// accumulators (as above); its consumers - the 1x1 data gradient and the 1x1 weight gradient - derive the
+// k's in their prologues (device_utils.h: fused_k), so no bn_bwd_prep launch separates them.
+struct FusedK {
+  const long long* acc;     // [R][2][acc_ld]: sum g, sum g*h   (nullptr: off)
+  int acc_ld;
+  const float* mean;        // forward statistics of this BN
+  const float* rstd;
+  const float* scale;       // gamma * rstd
+  double inv_count;         // 1 / pixels
+  float* dgamma;            // += by workgroup (0,0) of the data-gradient consumer (nullptr: not this kernel's job)
+  float* dbeta;
+};
+
 // out[M x N] (op)= rows(A)[M x taps*C] * W
 struct ConvGemmParams {
   RowSrc a;
   FusedBn bn;
+  FusedK fk;
   int M, C, N;        // pixels, channels per tap of the row source (GEMM K = taps*C), output channels
   int H, W;           // spatial size (3x3 taps only)
   int taps;           // 1 or 9 (3x3, stride 1, pad 1)
@@ -77,7 +93,7 @@ struct ConvGemmParams {
   int ldaux;
   const float* e0;
   const float* e1;
-  int stats;          // 0 none; 1: per-column sum(v), sum(v*v); 2: sum(g), sum(g*aux); 3: as 1 into bn.acc_out
+  int stats;          // 0 none; 1: per-column sum(v), sum(v*v); 2: sum(g), sum(g*aux); into stats_out, or bn.acc_out if set
   float* stats_out;   // [gridDim.x][2][N]
   // derived on the host (conv_bindings.cpp: finish_params)
   int kind;           // 0 FWD, 1 TDGRAD, 2 DGRAD3, 3 DGRAD1 (see conv_gemm.hip)
@@ -88,6 +104,7 @@ struct ConvGemmParams {
 
 // dW[N x taps*C] += dO^T[N x M] * rows(A)[M x taps*C]   (weight gradient; split over M, slab output)
 struct WgradParams {
+  FusedK fk;          // 1x1: dO = k0*X0 + k1*X1 + k2 with the k's derived from accumulators
   RowSrc d;           // dO source, N channels
   RowSrc a;           // activation source, C channels
   int M, C, N;

@@ -127,8 +127,21 @@ __global__ void __launch_bounds__(256) wgrad1x1_kernel(const WgradParams p) {
   const SrcDesc dd = src_desc(p.d), da = src_desc(p.a);
 
   const int q = 4 * (tid & 31);          // this thread's channel quad in both tiles (f & 31 == tid & 31)
-  const ColAffine kd = col_affine(p.d, n0 + q, n0 + q < p.N);
+  ColAffine kd = col_affine(p.d, n0 + q, n0 + q < p.N);
   const ColAffine ka = col_affine(p.a, c0 + q, c0 + q < p.C);
+  if (p.fk.acc != nullptr) {
+    // fused BN backward: dO = k0*g + k1*h + k2 with the k's derived here from the (sum g, sum g*h)
+    // accumulators the producing data-gradient kernel filled (no bn_bwd_prep launch in between)
+    float* kt = smem;                    // [3][128], dead before the first store_step
+    if (tid < 128) {
+      float k0 = 0.f, k1 = 0.f, k2 = 0.f, dg, db;
+      if (n0 + tid < p.N) fused_k(p.fk, n0 + tid, kStatReplicas, 1.0 / kStatScale, k0, k1, k2, dg, db);
+      kt[tid] = k0; kt[128 + tid] = k1; kt[256 + tid] = k2;
+    }
+    __syncthreads();
+    kd.s0 = ld4(kt + q); kd.s1 = ld4(kt + 128 + q); kd.s2 = ld4(kt + 256 + q);
+    __syncthreads();
+  }
   RawPix d_raw[4], a_raw[4];
   auto load_step = [&](int st) {
     const int mrow = mb + st * RK;

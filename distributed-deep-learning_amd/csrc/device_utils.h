@@ -34,4 +34,26 @@ __device__ __forceinline__ void bst4(rsrc_t r, unsigned off, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)off, 0, 0);
 }
 
+// BN-backward coefficients of channel c from the fused (sum g, sum g*h) accumulators (FusedK, conv_params.h):
+//   dgamma = rstd * (sum g*h - mean * sum g), dbeta = sum g,
+//   dh = k0*g + k1*h + k2:  k0 = sc, k1 = -sc*rstd*dgamma/M, k2 = -sc*dbeta/M + sc*rstd*mean*dgamma/M
+template <typename FK>
+__device__ __forceinline__ void fused_k(const FK& f, int c, int replicas, double inv_scale, float& k0, float& k1,
+                                        float& k2, float& dgamma, float& dbeta) {
+  long long s1 = 0, s2 = 0;
+  for (int r = 0; r < replicas; ++r) {
+    s1 += f.acc[(long)(2 * r) * f.acc_ld + c];
+    s2 += f.acc[(long)(2 * r + 1) * f.acc_ld + c];
+  }
+  const double sg = (double)s1 * inv_scale, sgx = (double)s2 * inv_scale;
+  const double mean = f.mean[c], rstd = f.rstd[c], sc = f.scale[c];
+  const double dgam = rstd * (sgx - mean * sg);
+  const double a = sg * f.inv_count, b = dgam * f.inv_count;
+  k0 = (float)sc;
+  k1 = (float)(-sc * b * rstd);
+  k2 = (float)(-sc * a + sc * b * rstd * mean);
+  dgamma = (float)dgam;
+  dbeta = (float)sg;
+}
+
 }  // namespace ddl

@@ -151,6 +151,9 @@ class _BlockFn(torch.autograd.Function):
         done = [None, None]
         min_rows = unit.stage.wgrad_min_rows
         bf = unit.stage.bf16
+        fused = unit.stage.fused_bwd
+        if fused:     # (sum g2, sum g2*h) accumulators: BN2-backward coefficients are derived by their consumers
+            acc_g = torch.zeros(L, ext.STAT_REPLICAS, 2, MID, dtype=torch.int64, device=buf.device)
         for l in range(L - 1, -1, -1):
             lay = unit.layers[l]
             C = C0 + GROWTH * l
@@ -165,7 +168,8 @@ class _BlockFn(torch.autograd.Function):
                 ev0.record(main)
             # 3x3 data gradient (+ ReLU/BN2 mask, sum g2, sum g2*h)
             st = ext.conv_gemm(dy, xs, ones[:GROWTH], nq[sl], np_[sl], False, M, H, W, 9, True,
-                               lay.w2, True, g2[par], True, False, h[l], sc2, sh2, 2, 0, bf)
+                               lay.w2, True, g2[par], True, False, h[l], sc2, sh2, 2, 0, bf,
+                               acc_out=acc_g[l] if fused else None)
             # 3x3 weight gradient
             if side is not None:
                 side.wait_event(ev0)
@@ -175,24 +179,31 @@ class _BlockFn(torch.autograd.Function):
             else:
                 ext.conv_wgrad(dy, xs, ones[:GROWTH], nq[sl], np_[sl], h[l], sc2, sh2, True, M, H, W, 9,
                                lay.gw2, min_rows)
-            ext.bn_bwd_prep(st, float(M), bn2[l, 0], bn2[l, 2], sc2, lay.gg2, lay.gb2,
-                            k[par, 0], k[par, 1], k[par, 2], MID, 0)
+            if fused:
+                kd = (None, None, None)
+                kf = dict(k_acc=acc_g[l], k_mean=bn2[l, 0], k_rstd=bn2[l, 2], k_scale=sc2, k_count=float(M))
+                kg = dict(k_dgamma=lay.gg2, k_dbeta=lay.gb2)
+            else:
+                ext.bn_bwd_prep(st, float(M), bn2[l, 0], bn2[l, 2], sc2, lay.gg2, lay.gb2,
+                                k[par, 0], k[par, 1], k[par, 2], MID, 0)
+                kd, kf, kg = (k[par, 0], k[par, 1], k[par, 2]), {}, {}
             # 1x1 weight gradient (activation re-normalised on the fly)
             if side is not None:
                 ev1 = torch.cuda.Event()
                 ev1.record(main)
                 side.wait_event(ev1)
                 with torch.cuda.stream(side):
-                    ext.conv_wgrad(g2[par], h[l], k[par, 0], k[par, 1], k[par, 2], buf2d[:, :C], sc1[l], sh1[l],
-                                   True, M, H, W, 1, lay.gw1, min_rows)
+                    ext.conv_wgrad(g2[par], h[l], *kd, buf2d[:, :C], sc1[l], sh1[l],
+                                   True, M, H, W, 1, lay.gw1, min_rows, **kf)
                     done[par] = torch.cuda.Event()
                     done[par].record(side)
             else:
-                ext.conv_wgrad(g2[par], h[l], k[par, 0], k[par, 1], k[par, 2], buf2d[:, :C], sc1[l], sh1[l],
-                               True, M, H, W, 1, lay.gw1, min_rows)
+                ext.conv_wgrad(g2[par], h[l], *kd, buf2d[:, :C], sc1[l], sh1[l],
+                               True, M, H, W, 1, lay.gw1, min_rows, **kf)
             # 1x1 data gradient: dh = k0*g2 + k1*h + k2 on the fly; epilogue: mask, dBuf += sc1*g1, sums
-            st1 = ext.conv_gemm(g2[par], h[l], k[par, 0], k[par, 1], k[par, 2], False, M, H, W, 1, False,
-                                lay.w1, True, d2d[:, :C], True, True, buf2d[:, :C], sc1[l], sh1[l], 2, 0, bf)
+            st1 = ext.conv_gemm(g2[par], h[l], *kd, False, M, H, W, 1, False,
+                                lay.w1, True, d2d[:, :C], True, True, buf2d[:, :C], sc1[l], sh1[l], 2, 0, bf,
+                                **kf, **kg)
             ext.bn_bwd_prep(st1, float(M), stats[0], stats[2], sc1[l], lay.gg1, lay.gb1, None, nq, np_, C, 1)
         if side is not None:
             main.wait_stream(side)
@@ -446,7 +457,13 @@ class NativeDenseNetStage(nn.Module):
         # rounded at the LDS write, fp32 accumulate); storage, BN statistics, weight gradients, stem, head
         # and Adam stay fp32.  Not the reference's numerics -- never the default, never the headline.
         self.bf16 = dtype == "bf16"
+        # Fused BN statistics (csrc/conv_params.h FusedBn / FusedK): forward on by default (2 bn_prep launches
+        # per dense layer leave the single-stream forward chain: 10.41 -> 9.92 ms/step at batch 30).  The
+        # backward variant (BN2 coefficients derived inside the 1x1 dgrad / wgrad) removes 58 more launches
+        # but its prologue work outweighs them once the two backward streams overlap inside a hipGraph
+        # (10.23 ms), so it is opt-in: DDL_FUSED_BWD=1 (it does win with eager launches).
         self.fused_stats = os.environ.get("DDL_FUSED_STATS", "1") == "1"
+        self.fused_bwd = os.environ.get("DDL_FUSED_BWD", "0") == "1"
         ops.require_ext()
         device = torch.device(device)
         if device.type != "cuda":

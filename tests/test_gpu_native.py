@@ -174,9 +174,11 @@ def _ref_stage(units, dev, seed=0):
     return ref
 
 
-def _native_from(ref, units, dev):
+def _native_from(ref, units, dev, fused=None):
     from ddl.models.native_densenet import NativeDenseNetStage
     nat = NativeDenseNetStage(units, 5, dev)
+    if fused is not None:             # (forward, backward) fused-statistics switches
+        nat.fused_stats, nat.fused_bwd = fused
     nat.import_state_dict(ref.state_dict())
     return nat
 
@@ -186,12 +188,12 @@ def _relerr(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
 
 
-def _compare_unit(dev, units, in_shape_nchw, tol=2e-5, slack=4.0, global_l2=False):
+def _compare_unit(dev, units, in_shape_nchw, tol=2e-5, slack=4.0, global_l2=False, fused=None):
     """Native engine vs the PyTorch model, both judged against an fp64 run of the PyTorch model.
     Deep random-init BN stacks on tiny batches are ill-conditioned (ReLU masks flip on 1e-7
     perturbations), so the criterion is: native error <= max(tol, slack * error of torch fp32)."""
     ref = _ref_stage(units, dev)
-    nat = _native_from(ref, units, dev)
+    nat = _native_from(ref, units, dev, fused)
     ref64 = _ref_stage(units, dev).double()
     ref64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
     x = _rand(*in_shape_nchw, dev=dev, seed=5)
@@ -239,12 +241,23 @@ def _compare_unit(dev, units, in_shape_nchw, tol=2e-5, slack=4.0, global_l2=Fals
     assert _relerr(yn if last else yn.permute(0, 3, 1, 2), y64) <= max(tol, slack * _relerr(yr, y64)), "eval forward"
 
 
-def test_dense_block_fwd_bwd(dev):
-    _compare_unit(dev, ("denseblock1",), (2, 64, 16, 16))
+# statistics paths: per-tile tables + bn_prep launches / fused forward (default) / fused forward + backward
+STAT_MODES = [(False, False), (True, False), (True, True)]
 
 
-def test_dense_block4_small_spatial(dev):
-    _compare_unit(dev, ("denseblock4",), (3, 512, 7, 7))
+@pytest.mark.parametrize("fused", STAT_MODES)
+def test_dense_block_fwd_bwd(dev, fused):
+    _compare_unit(dev, ("denseblock1",), (2, 64, 16, 16), fused=fused)
+
+
+@pytest.mark.parametrize("fused", STAT_MODES)
+def test_dense_block4_small_spatial(dev, fused):
+    _compare_unit(dev, ("denseblock4",), (3, 512, 7, 7), fused=fused)
+
+
+def test_dense_block_many_row_tiles(dev):
+    """Enough row tiles that every statistics-accumulator replica takes atomics from several workgroups."""
+    _compare_unit(dev, ("denseblock1",), (6, 64, 56, 56), fused=(True, True))
 
 
 def test_transition_fwd_bwd(dev):
