@@ -60,6 +60,65 @@ def test_conv3x3_fwd_slice_write(dev, B, H, W, bm):
     torch.testing.assert_close(st[:, 0].sum(0).double(), ref.sum(0), rtol=1e-4, atol=1e-2)
 
 
+@pytest.mark.parametrize("M,C,Cf,new0,taps,HW", [(3136, 96, 256, 64, 1, 56), (300, 64, 256, 64, 1, 0), (94, 992, 1024, 960, 1, 0),
+                                                  (12544, 128, 128, 0, 9, 112), (392, 128, 128, 0, 9, 14)])
+def test_conv_fwd_fused_statistics(dev, M, C, Cf, new0, taps, HW):
+    """conv_fwd_fused: BN scale/shift derived in the prologue from the int64 fixed-point accumulators (channels
+    >= new0) or the float tables (channels < new0); column sums of the output added to acc_out; workgroup (0,0)
+    writes the backward tables and the running statistics.  Reference: fp64 PyTorch."""
+    from ddl import ops
+    ext = ops.require_ext()
+    R, S = ext.STAT_REPLICAS, 2.0 ** 28
+    H = W = HW if taps == 9 else 1
+    if taps == 9:
+        M = (M // (H * W)) * H * W
+    N = 128 if taps == 1 else 32
+    buf = _rand(M, Cf, dev=dev, seed=1) * 1.5 + 0.3
+    x = buf[:, :C]
+    gamma, beta = _rand(C, dev=dev, seed=2).abs() + 0.5, _rand(C, dev=dev, seed=3)
+    w = _rand(N, taps * C, dev=dev, seed=4, scale=0.05)
+    x64 = x.double()
+    mean64, var64 = x64.mean(0), x64.var(0, unbiased=False)
+    # accumulators of the new channels, spread unevenly over the replicas; tables for the old ones
+    acc_in = torch.zeros(R, 2, Cf, dtype=torch.int64, device=dev)
+    rows = torch.arange(M, device=dev) % R
+    for r in range(R):
+        sel = x64[rows == r]
+        acc_in[r, 0, :C] = torch.round(sel.sum(0) * S).long()
+        acc_in[r, 1, :C] = torch.round((sel * sel).sum(0) * S).long()
+    acc_in[:, :, :new0] = 0                                   # must not be read
+    mean_t, var_t, rstd_t = torch.zeros(Cf, device=dev), torch.zeros(Cf, device=dev), torch.zeros(Cf, device=dev)
+    mean_t[:new0], var_t[:new0] = mean64[:new0].float(), var64[:new0].float()
+    rstd_t[:new0] = (1.0 / torch.sqrt(var64[:new0] + 1e-5)).float()
+    rm, rv = _rand(C, dev=dev, seed=5), _rand(C, dev=dev, seed=6).abs() + 0.5
+    rm0, rv0 = rm.clone(), rv.clone()
+    sc_o, sh_o = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    out = torch.full((M, N), float("nan"), device=dev)
+    acc_out = torch.zeros(R, 2, N + 32, dtype=torch.int64, device=dev)
+    ext.conv_fwd_fused(x, acc_in, new0, gamma, beta, rm, rv, sc_o, sh_o, mean_t, var_t, rstd_t, float(M), 0.1, 1e-5,
+                       M, H, W, taps, w, out, acc_out[:, :, 32:], 0, False)
+    sc64 = gamma.double() / torch.sqrt(var64 + 1e-5)
+    sh64 = beta.double() - mean64 * sc64
+    a64 = torch.relu(x64 * sc64 + sh64)
+    if taps == 1:
+        ref = a64 @ w.double().t()
+    else:
+        B = M // (H * W)
+        w4 = w.double().view(N, 3, 3, C).permute(0, 3, 1, 2)
+        ref = F.conv2d(a64.view(B, H, W, C).permute(0, 3, 1, 2), w4, padding=1).permute(0, 2, 3, 1).reshape(M, N)
+    torch.testing.assert_close(out.double(), ref, rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(sc_o.double(), sc64, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(sh_o.double(), sh64, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(mean_t[:C].double(), mean64, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rstd_t[:C].double(), 1.0 / torch.sqrt(var64 + 1e-5), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rm.double(), 0.9 * rm0.double() + 0.1 * mean64, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rv.double(), 0.9 * rv0.double() + 0.1 * var64 * M / (M - 1), rtol=1e-5, atol=1e-6)
+    assert int(acc_out[:, :, :32].abs().sum()) == 0           # the column slice next door is untouched
+    got = acc_out[:, :, 32:].sum(0).double() / S
+    torch.testing.assert_close(got[0], out.double().sum(0), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(got[1], (out.double() ** 2).sum(0), rtol=1e-5, atol=1e-3)
+
+
 def _bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float64)
 
