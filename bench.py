@@ -162,6 +162,7 @@ def main() -> None:
             "impl": impl,
             "launch": graph_mode,
             "grad_sync": "zero1 rs+ag(params)" if a.zero1 else "bucketed reduce-scatter + all-gather",
+            "reducer": ("native" if getattr(getattr(strat, "dp", None), "_native", None) is not None else "python"),
         },
     }
     if a.profile:

@@ -31,6 +31,7 @@ shard (``FusedAdam(shard=...)``), then all-gather the *parameters* - same bytes 
 """
 from __future__ import annotations
 
+import os
 import time
 from contextlib import contextmanager
 from typing import Callable, List, Optional
@@ -38,7 +39,7 @@ from typing import Callable, List, Optional
 import torch
 import torch.distributed as dist
 
-from .. import comm
+from .. import comm, ops
 from ..utils.arena import FlatArena, FlatBuffers, reverse_named_parameters
 
 
@@ -84,6 +85,23 @@ class DataParallelEngine:
         self._slot_segment = [s.segment for s in self.arena.slots]
         self._reset_counters()
 
+        # Native bucket reducer (csrc/reducer.cpp): on a GPU with an RCCL group the bookkeeping + fences +
+        # collectives of the gradient path run in C++; gloo (CPU tests, several ranks on one GPU) keeps
+        # the Python path below, which is the same algorithm.
+        self._native = None
+        if (self.on_cuda and not self.single and comm.backend_of(group) == "nccl" and ops.have_ext()
+                and os.environ.get("DDL_NATIVE_REDUCER", "1") == "1"):
+            segs = self.arena.segments
+            pending = [sum(1 for i in seg.slots if self.arena.params[i].requires_grad) for seg in segs]
+            cs = self.comm_stream
+            self._native = ops.require_ext().BucketReducer(
+                self.arena.flat_grad, [s.start for s in segs], [s.end for s in segs], list(self._slot_segment),
+                pending, group if group is not None else dist.group.WORLD, self.rank, self.world, bool(zero1),
+                grad_sync == "allreduce", bool(debug_sync), bool(profiler is not None and profiler.enabled),
+                cs.stream_id, cs.device_index, cs.device_type)
+            if profiler is not None:
+                profiler.add_source("rccl", self._native.drain_ms)
+
         self.broadcast_state()
         if register_hooks:
             for i, p in enumerate(self.arena.params):
@@ -126,6 +144,9 @@ class DataParallelEngine:
     def param_ready(self, slot_index: int) -> None:
         """The gradient of arena slot ``slot_index`` is final (autograd hook, or the native
         engine's per-unit callback for gradients it writes into the arena itself)."""
+        if self._native is not None:
+            self._native.param_ready(slot_index)
+            return
         if not self._armed:
             return
         k = self._slot_segment[slot_index]
@@ -142,19 +163,28 @@ class DataParallelEngine:
     def no_sync(self):
         """Accumulate locally (micro-batches 0..M-2 of a pipeline step)."""
         prev, self._armed = self._armed, False
+        if self._native is not None:
+            self._native.arm(False, False)
         try:
             yield
         finally:
             self._armed = prev
+            if self._native is not None:
+                self._native.arm(prev, False)
 
     def arm(self, armed: bool = True) -> None:
         self._armed = armed
+        if self._native is not None:
+            self._native.arm(armed, armed)
         if armed:
             self._reset_counters()
 
     def segment_ready(self, k: int) -> None:
         """All gradients of arena segment ``k`` are final: launch its collective(s) now.
         Called by the autograd hooks, or directly by the native engine's backward."""
+        if self._native is not None:
+            self._native.segment_ready(k)
+            return
         if self._launched[k] or not self._armed:
             return
         self._launched[k] = True
@@ -206,6 +236,9 @@ class DataParallelEngine:
     def finish_grad_sync(self) -> None:
         """Make the compute stream wait for every outstanding bucket; launch stragglers
         (segments whose hooks did not all fire, e.g. unused parameters)."""
+        if self._native is not None:
+            self._native.finish()
+            return
         if self._armed:
             for k in range(len(self.arena.segments)):
                 if not self._launched[k]:

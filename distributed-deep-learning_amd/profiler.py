@@ -36,6 +36,12 @@ class StepProfiler:
         self.totals_ms: Dict[str, float] = defaultdict(float)
         self.counts: Dict[str, int] = defaultdict(int)
         self.steps = 0
+        self._sources: List[Tuple[str, object]] = []             # (name, fn() -> ms since the last call)
+
+    def add_source(self, name: str, fn) -> None:
+        """A span total measured elsewhere (the native bucket reducer times its RCCL calls itself)."""
+        if self.enabled:
+            self._sources.append((name, fn))
 
     # ---- spans -----------------------------------------------------------------------
     def begin(self, name: str, stream=None):
@@ -75,6 +81,11 @@ class StepProfiler:
 
     # ---- results ---------------------------------------------------------------------
     def collect(self) -> None:
+        for name, fn in self._sources:
+            ms = float(fn())
+            if ms > 0:
+                self.totals_ms[name] += ms
+                self.counts[name] += 1
         if self.cuda and self._open:
             torch.cuda.synchronize(self.device)
             for name, s, e in self._open:

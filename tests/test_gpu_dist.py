@@ -211,3 +211,24 @@ def test_bench_rccl_world_of_one_forced_collectives(tmp_path, extra):
     assert rec["n_gpus"] == 1 and rec["value"] > 0
     assert rec["config"]["launch"] == ("off" if "--no-graph" in extra else "hipGraph"), out[-3000:]
     assert rec["profile"]["rccl_ms_per_step"] > 0, rec["profile"]
+    assert rec["config"]["reducer"] == "native"          # csrc/reducer.cpp drove the RCCL calls
+
+
+@pytest.mark.gpu
+def test_native_reducer_matches_python_reducer(tmp_path):
+    """csrc/reducer.cpp vs the Python bucket path of parallel/dp.py: same seed, same batches, RCCL world of one
+    with forced collectives, eager launches so the engine's per-unit callbacks drive param_ready; the native
+    engine is bit-deterministic, so the epoch loss must be identical."""
+    import re
+    losses = []
+    for native in ("1", "0"):
+        os.environ.update(DDL_FORCE_COLLECTIVES="1", DDL_NATIVE_REDUCER=native)
+        try:
+            out = _torchrun(1, "ddp.py", [*SMALL, "--batch-size", "8", "--seed", "7", "--hip-graph", "false"], tmp_path)
+        finally:
+            os.environ.pop("DDL_FORCE_COLLECTIVES", None)
+            os.environ.pop("DDL_NATIVE_REDUCER", None)
+        m = re.search(r"Epoch 0 \| Loss: ([0-9.eE+-]+)", out)
+        assert m, out[-2000:]
+        losses.append(float(m.group(1)))
+    assert losses[0] == losses[1], losses
