@@ -113,6 +113,7 @@ def main() -> None:
               f"falling back to eager launches", file=sys.stderr, flush=True)
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
+        os.environ["DDL_NATIVE_REDUCER"] = "0"      # most conservative path: eager launches, Python bucket reducer
         strat = make_strategy(False)
         strat.model.train()
         for i in range(PRIME + a.warmup):
