@@ -1,0 +1,242 @@
+// Forward 3x3 convolution (stride 1, pad 1) as an implicit GEMM whose input is staged ONCE per workgroup.
+//
+// conv_gemm.hip treats the nine taps as nine K slabs and re-stages the (shifted) input rows for each
+// of them: every input element is loaded from L2, pushed through the BN+ReLU prologue and written to
+// LDS nine times.  With N = 32 output channels that staging work, not the MFMA loop, bounds the kernel
+// (rocprofv3: 10 VALU instructions per MFMA, 44 % MFMA utilisation on the 56x56 maps).
+//
+// A row tile is BM consecutive pixels of the flattened NHWC tensor, so the rows any tap can touch are
+// the contiguous range [m0 - W - 1, m0 + BM + W + 1).  This kernel stages that range once per
+// 32-channel chunk (prologue applied once per element), and every tap reads its operand rows from
+// LDS at a constant row offset (dy*W + dx).  A (pixel, tap) pair that leaves the image is zeroed when
+// the MFMA operand is read (one v_cndmask per operand register, from the lane's 9-bit tap mask).
+// Weights are staged per tap through a double buffer (a whole filter row per barrier was tried: the
+// extra LDS costs a workgroup per CU and more than the saved barriers).  Output + statistics: the shared
+// epilogue (conv_common.h), so the result layout is identical to conv_gemm's forward kind.
+//
+// Measured (MI355X, fp32): 56x56x128 -> 32 at batch 30: 104 -> 78 us (89 TFLOP/s); batch 128: 406 -> 334 us,
+// 28x28: 108 -> 93 us.  The 3x3 data gradient (N = 128, K = 288) was tried on the same scheme and is not
+// faster than its conv_gemm tiles - its staging was never the bottleneck - so it stays there.
+#include "conv_common.h"
+#include "conv_params.h"
+#include "ddl_kernels.h"
+#include "device_utils.h"
+
+namespace ddl {
+
+namespace {
+
+constexpr int HALO_MAXW = 56;            // widest feature map of DenseNet-121 after the stem
+
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN) conv3x3_halo_kernel(const ConvGemmParams p) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  constexpr int LDA = 36;                // row stride of the K-contiguous LDS images: 32 channels + 4 pad
+  constexpr int RMAX = BM + 2 * HALO_MAXW + 2;
+  constexpr int PA = (RMAX * 8 + NT - 1) / NT;        // float4 per thread for the widest range
+  constexpr int PB = (BN * 8) / NT;                   // float4 per thread for one tap of weights
+  constexpr int B_ELEMS = BN * LDA;
+  static_assert((BN * 8) % NT == 0 && NT % 8 == 0, "a weight tap must divide over the workgroup");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const bool affine = p.a.s0 != nullptr || p.bn.acc != nullptr;
+  const int soff = affine ? 2 * p.C : 0;
+  float* scs = smem;                     // BN scale / shift of the C input channels
+  float* shs = smem + p.C;
+  const int halo = p.W + 1;
+  const int R = BM + 2 * halo;           // staged pixel rows
+  float* As = smem + soff;               // [R][LDA]
+  float* Bs = As + R * LDA;              // [2][B_ELEMS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wmn = tid >> 6;
+  const int wm = wmn / WN, wn = wmn - wm * WN;
+  const int li = lane & 31, lh = lane >> 5;
+  int tile_x;
+  {   // XCD-aware tile order (see conv_gemm.hip)
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    tile_x = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int m0 = tile_x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int chunks = p.C >> 5;
+
+  const rsrc_t rA = make_rsrc(p.a.X0, p.a.bytes0);
+  const rsrc_t rW = make_rsrc(p.Wt, p.wbytes);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging roles ---------------------------------------------------------------------------
+  const int cq = tid & 7;                // channel quad of the chunk this thread stages (NT % 8 == 0)
+  unsigned a_off[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int r = (tid + i * NT) >> 3;
+    const int m = m0 - halo + r;
+    a_off[i] = (r < R && m >= 0 && m < p.M) ? (unsigned)m * (unsigned)(p.a.ld0 * 4) + (unsigned)(16 * cq) : OOB;
+  }
+  // ---- compute roles: 9-bit tap mask of this lane's pixel in each of its row blocks ------------------
+  unsigned bits[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + (wm * TM + i) * 32 + li;
+    unsigned b = 0;
+    if (m < p.M) {
+      const int rem = m % (p.H * p.W);
+      const int y = rem / p.W, x = rem - y * p.W;
+      const unsigned yb = (y > 0) | 2u | ((unsigned)(y < p.H - 1) << 2);
+      const unsigned xb = (x > 0) | 2u | ((unsigned)(x < p.W - 1) << 2);
+      b = ((yb & 1u) ? xb : 0u) | ((yb & 2u) ? (xb << 3) : 0u) | ((yb & 4u) ? (xb << 6) : 0u);
+    }
+    bits[i] = b;
+  }
+
+  f32x4 a_v[PA], b_reg[PB];
+  auto load_a = [&](int chunk) {
+    const unsigned dc = (unsigned)(chunk * 128);        // 32 channels * 4 bytes
+#pragma unroll
+    for (int i = 0; i < PA; ++i) a_v[i] = bld4(rA, a_off[i] == OOB ? OOB : a_off[i] + dc);
+  };
+  auto store_a = [&](int chunk) {
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = zero4;
+    if (affine) {
+      sc = ld4(scs + chunk * 32 + 4 * cq);
+      sh = ld4(shs + chunk * 32 + 4 * cq);
+    }
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int r = (tid + i * NT) >> 3;
+      f32x4 v = a_v[i];
+      if (affine) {
+        v = sc * v + sh;
+        if (p.a.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+      }
+      // rows outside the tensor hold finite garbage (the prologue of zeros); every (pixel, tap) pair that
+      // could read them is masked by `bits`
+      if (r < R) *reinterpret_cast<f32x4*>(As + r * LDA + 4 * cq) = v;
+    }
+  };
+  auto load_b = [&](int chunk, int tap) {              // weights [N][9][C], one tap, 32 channels
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int f = tid + i * NT;
+      const int n = n0 + (f >> 3);
+      const unsigned off = (unsigned)((n * p.ldb + tap * p.C + chunk * 32 + 4 * (f & 7)) * 4);
+      b_reg[i] = bld4(rW, n < p.N ? off : OOB);
+    }
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int f = tid + i * NT;
+      *reinterpret_cast<f32x4*>(Bs + buf * B_ELEMS + (f >> 3) * LDA + 4 * (f & 7)) = b_reg[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto compute = [&](int tap, int buf) {
+    const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;
+    const int toff = (ty - 1) * p.W + (tx - 1);        // row offset of this tap in the flattened tensor
+    const float* Ab = As + (halo + toff + wm * TM * 32 + li) * LDA + 4 * lh;
+    const float* Bb = Bs + buf * B_ELEMS + (wn * TN * 32 + li) * LDA + 4 * lh;
+    bool on[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) on[i] = (bits[i] >> tap) & 1u;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        af[i] = ld4(Ab + i * 32 * LDA + 8 * s);
+        af[i] = on[i] ? af[i] : zero4;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = ld4(Bb + j * 32 * LDA + 8 * s);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (n0 + (wn * TN + j) * 32 >= p.N) continue;      // wave-uniform: sub-tile beyond N
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- main loop: chunk = 32 input channels; per chunk the range is staged once, then nine taps ------
+  load_a(0);
+  load_b(0, 0);
+  conv_fill_tables<NT, 0>(p, affine, scs, shs, scs, tid);        // scale / shift tables (fused statistics)
+  __syncthreads();
+  store_a(0);
+  store_b(0);
+  __syncthreads();
+  int step = 0;                                                   // chunk * 9 + tap
+  for (int chunk = 0; chunk < chunks; ++chunk) {
+    const bool more = chunk + 1 < chunks;
+    if (more) load_a(chunk + 1);                                  // in flight under the nine taps
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap, ++step) {
+      const bool next = tap < 8 || more;
+      if (next) load_b(tap < 8 ? chunk : chunk + 1, tap < 8 ? tap + 1 : 0);
+      compute(tap, step & 1);
+      if (next) store_b((step + 1) & 1);
+      __syncthreads();
+    }
+    if (more) {
+      store_a(chunk + 1);
+      __syncthreads();
+    }
+  }
+  conv_epilogue<BM, BN, WM, WN, NT, 0>(p, acc, smem, m0, n0, tile_x, tid, 0, wmn);
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch_halo(const ConvGemmParams& p, hipStream_t s) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr size_t b_elems = (size_t)BN * 36;
+  constexpr size_t epi = (size_t)WM * WN * 32 * 36 * sizeof(float);
+  constexpr size_t sta = (size_t)2 * WM * 8 * BN * sizeof(float);
+  constexpr size_t lds_max = ((size_t)(BM + 2 * HALO_MAXW + 2) * 36 + 2 * b_elems + 2 * kMaxAffineC) * sizeof(float);
+  const bool tables = p.a.s0 != nullptr || p.bn.acc != nullptr;
+  const size_t stage = ((tables ? (size_t)2 * p.C : 0) + (size_t)(BM + 2 * p.W + 2) * 36 + 2 * b_elems) * sizeof(float);
+  size_t lds = stage > epi ? stage : epi;
+  if (sta > lds) lds = sta;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, WM, WN>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.N + BN - 1) / BN));
+  hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, WM, WN>), grid, dim3(NT), lds, s, p);
+}
+
+}  // namespace
+
+// Which problems take this kernel: fp32 forward 3x3 with N <= 32, feature maps up to 56 wide and - unless
+// `any_size` (tests) - enough 128-row tiles to fill the chip; the small-M layers keep conv_gemm's K-split tiles
+// (64-row halo tiles are two waves per workgroup: 51 vs 31 us on block 2 at batch 30).
+// Returns the row-tile height (0: not eligible).
+int conv3x3_halo_bm(const ConvGemmParams& p, bool any_size) {
+  if (p.taps != 9 || p.kind != 0 || p.bf16 || p.W > HALO_MAXW || p.W < 1 || (p.C & 31)) return 0;
+  if (p.N > 32 || p.C > kMaxAffineC) return 0;
+  return ((p.M + 127) / 128 >= 384 || any_size) ? 128 : 0;
+}
+
+void launch_conv3x3_halo(const ConvGemmParams& p, int bm, hipStream_t s) {
+  (void)bm;
+  launch_halo<128, 32, 4, 1>(p, s);
+}
+
+}  // namespace ddl

@@ -150,7 +150,7 @@ at::Tensor conv_gemm(const at::Tensor& x0, const OptT& x1, const OptT& s0, const
     p.bn.acc_out = reinterpret_cast<long long*>(acc_out->data_ptr<int64_t>());
     p.bn.acc_out_ld = (int)acc_out->stride(1);
   } else if (stats_mode) {
-    const int G = ddl::conv_gemm_grid_x((int)M, (int)N, (int)force_bm);
+    const int G = ddl::conv_gemm_grid_x(p, (int)force_bm);
     stats = at::empty({G, 2, N}, x0.options());
     p.stats_out = stats.data_ptr<float>();
   }

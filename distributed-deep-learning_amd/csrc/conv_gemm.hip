@@ -30,9 +30,12 @@
 // writes) and are read with four conflict-free ds_read_b32 instead of being transposed.
 // fp32 MFMA issues once per 64 cycles, so LDS and VALU (the fused prologue) are far from
 // limiting; what matters is keeping every SIMD's MFMA queue fed.
+#include <cstdlib>
+
 #include "conv_params.h"
 #include "ddl_kernels.h"
 #include "device_utils.h"
+#include "conv_common.h"
 
 namespace ddl {
 
@@ -304,61 +307,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
   };
 
   // ---- forward BN prologue tables -> LDS (runs while the first slab's global loads are in flight) ----
-  auto bn_tables = [&]() {
-    if (!LDS_TABLES || !affine) return;
-    if (KIND == 3) {
-      const bool writer = blockIdx.x == 0 && blockIdx.y == 0 && p.fk.dgamma != nullptr;
-      for (int c = tid; c < p.C; c += NT) {
-        float k0, k1, k2;
-        if (p.fk.acc != nullptr) {
-          float dg, db;
-          fused_k(p.fk, c, kStatReplicas, 1.0 / kStatScale, k0, k1, k2, dg, db);
-          if (writer) { p.fk.dgamma[c] += dg; p.fk.dbeta[c] += db; }
-        } else {
-          k0 = p.a.s0[c]; k1 = p.a.s1[c]; k2 = p.a.s2[c];
-        }
-        scs[c] = k0; shs[c] = k2; k1s[c] = k1;
-      }
-      return;
-    }
-    if (p.bn.acc == nullptr) {
-      for (int c = tid; c < p.C; c += NT) { scs[c] = p.a.s0[c]; shs[c] = p.a.s2[c]; }
-      return;
-    }
-    const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
-    for (int c = tid; c < p.C; c += NT) {
-      float meanf, varf, rstd;
-      if (c < p.bn.new0) {                 // finalised by an earlier consumer
-        meanf = p.bn.mean[c]; varf = p.bn.var[c]; rstd = p.bn.rstd[c];
-      } else {
-        long long s1 = 0, s2 = 0;
-#pragma unroll
-        for (int r = 0; r < kStatReplicas; ++r) {
-          s1 += p.bn.acc[(long)(2 * r) * p.bn.acc_ld + c];
-          s2 += p.bn.acc[(long)(2 * r + 1) * p.bn.acc_ld + c];
-        }
-        const double mean = (double)s1 * p.bn.inv_count;
-        double var = (double)s2 * p.bn.inv_count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        meanf = (float)mean; varf = (float)var;
-        rstd = __frsqrt_rn(varf + p.bn.eps);                     // + one Newton step: full fp32 accuracy
-        rstd = rstd * (1.5f - 0.5f * (varf + p.bn.eps) * rstd * rstd);
-        if (writer) { p.bn.mean[c] = meanf; p.bn.var[c] = varf; p.bn.rstd[c] = rstd; }
-      }
-      const float sc = p.bn.gamma[c] * rstd;
-      const float sh = p.bn.beta[c] - meanf * sc;
-      scs[c] = sc;
-      shs[c] = sh;
-      if (writer) {
-        p.bn.scale_out[c] = sc;
-        p.bn.shift_out[c] = sh;
-        if (p.bn.run_mean != nullptr) {
-          p.bn.run_mean[c] = (1.f - p.bn.momentum) * p.bn.run_mean[c] + p.bn.momentum * meanf;
-          p.bn.run_var[c] = (1.f - p.bn.momentum) * p.bn.run_var[c] + p.bn.momentum * varf * p.bn.unbias;
-        }
-      }
-    }
-  };
+  auto bn_tables = [&]() { conv_fill_tables<NT, KIND>(p, affine, scs, shs, k1s, tid); };
 
   // ---- main loop: register-staged; NBUF = 2: one barrier per slab, NBUF = 1: half the LDS
   // (more workgroups per CU hide the extra barrier and every other latency) -------------------
@@ -428,93 +377,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
     __syncthreads();
   }
 
-  // ---- epilogue (wave group ks == 0 holds the result) -----------------------------------------
-  // The MFMA C/D layout gives a lane 16 values of ONE column (rows strided by the row pitch): stored
-  // as is, a 32x32 tile costs 16 scalar stores (+ 32 scalar loads for the masked / accumulating
-  // kinds).  Each wave instead transposes its tile through LDS (the staging area is free now) so that
-  // a lane owns 4 consecutive columns of 4 rows: 4 dwordx4 loads / stores per tile and operand.
-  // Rows >= M and columns >= N fall outside the descriptors (loads give 0, stores are dropped) and
-  // their accumulators are exactly 0 (zeroed operand rows / weight columns): no per-element predicates.
-  constexpr int TLD = 36;                  // transposition image row stride (floats)
-  f32x4 st1[TN], st2[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) { st1[j] = zero4; st2[j] = zero4; }
-  const int erow = lane >> 3, ecq = lane & 7;      // epilogue role: row (+8p) and column quad of the tile
-  if (ks == 0) {
-    const rsrc_t rO = make_rsrc(p.out, p.obytes);
-    const rsrc_t rX = make_rsrc(EPM ? p.aux : p.out, EPM ? p.auxbytes : p.obytes);
-    float* T = smem + wmn * (32 * TLD);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + (wn * TN + j) * 32 + 4 * ecq;
-      const bool colok = col < p.N;        // N % 4 == 0: a column quad is valid or invalid as a whole
-      f32x4 e0v = {1.f, 1.f, 1.f, 1.f}, e1v = zero4;
-      if (EPM || EPA) {
-        e0v = ld4(p.e0 + (colok ? col : 0));
-        if (EPM) e1v = ld4(p.e1 + (colok ? col : 0));
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lh) * TLD + li] = acc[i][j][r];
-        const unsigned row0 = (unsigned)(m0 + (wm * TM + i) * 32 + erow);
-        const unsigned obase = colok ? (row0 * (unsigned)p.ldo + (unsigned)col) * 4u : OOB;
-        const unsigned xbase = colok ? (row0 * (unsigned)p.ldaux + (unsigned)col) * 4u : OOB;
-        f32x4 axv[4], oldv[4], v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {      // every read of the tile (mask operand, old dBuf) ahead of the stores
-          axv[q] = EPM ? bld4(rX, xbase + (unsigned)(8 * q * p.ldaux * 4)) : zero4;
-          oldv[q] = EPA ? bld4(rO, obase + (unsigned)(8 * q * p.ldo * 4)) : zero4;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = ld4(T + (erow + 8 * q) * TLD + 4 * ecq);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 g = v[q];
-          if (EPM) {
-            const f32x4 z = e0v * axv[q] + e1v;
-            g.x = z.x > 0.f ? g.x : 0.f; g.y = z.y > 0.f ? g.y : 0.f;
-            g.z = z.z > 0.f ? g.z : 0.f; g.w = z.w > 0.f ? g.w : 0.f;
-            st1[j] += g;
-            st2[j] += g * axv[q];
-          } else {
-            st1[j] += g;
-            st2[j] += g * g;
-          }
-          bst4(rO, obase + (unsigned)(8 * q * p.ldo * 4), EPA ? e0v * g + oldv[q] : g);
-        }
-      }
-    }
-  }
-  if (p.stats) {
-    // per-lane column-quad sums -> red[which][row group (WM * 8)][BN] -> one sum per column
-    constexpr int RG = WM * 8;
-    float* red = smem;
-    __syncthreads();                       // transposition images are dead
-    if (ks == 0) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int c = (wn * TN + j) * 32 + 4 * ecq;
-        *reinterpret_cast<f32x4*>(red + (0 * RG + wm * 8 + erow) * BN + c) = st1[j];
-        *reinterpret_cast<f32x4*>(red + (1 * RG + wm * 8 + erow) * BN + c) = st2[j];
-      }
-    }
-    __syncthreads();
-    for (int c = tid; c < 2 * BN; c += NT) {
-      const int which = c / BN, cc = c - which * BN;
-      if (n0 + cc < p.N) {
-        float s = 0.f;
-#pragma unroll
-        for (int g = 0; g < RG; ++g) s += red[(which * RG + g) * BN + cc];
-        if ((KIND == 0 || KIND == 2) && p.bn.acc_out != nullptr) {   // fused statistics: fixed-point integer atomics
-          __hip_atomic_fetch_add(p.bn.acc_out + (long)(2 * (tile_x & (kStatReplicas - 1)) + which) * p.bn.acc_out_ld + n0 + cc,
-                                 __double2ll_rn((double)s * kStatScale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-          p.stats_out[((long)tile_x * 2 + which) * p.N + n0 + cc] = s;
-        }
-      }
-    }
-  }
+  conv_epilogue<BM, BN, WM, WN, NT, KIND>(p, acc, smem, m0, n0, tile_x, tid, ks, wmn);
 }
 
 template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF, int KIND, bool BF>
@@ -632,13 +495,24 @@ int pick_cfg(int M, int N, int force) {
 
 }  // namespace
 
-int conv_gemm_grid_x(int M, int N, int force) {
-  const int bm = kCfg[pick_cfg(M, N, force)].bm;
-  return (M + bm - 1) / bm;
+// `force` == 2000 sends an eligible 3x3 problem to the halo kernel whatever its size, any other non-zero
+// value keeps it on the conv_gemm tiles (tests / bench/kernel_bench.py); DDL_HALO=0 disables the halo kernel.
+static int halo_bm(const ConvGemmParams& p, int force) {
+  static const bool enabled = [] { const char* e = getenv("DDL_HALO"); return !(e && e[0] == '0'); }();
+  if (!enabled || (force != 0 && force != 2000)) return 0;
+  return conv3x3_halo_bm(p, force == 2000);
+}
+
+int conv_gemm_grid_x(const ConvGemmParams& p, int force) {
+  int bm = halo_bm(p, force);
+  if (!bm) bm = kCfg[pick_cfg(p.M, p.N, force == 2000 ? 0 : force)].bm;
+  return (p.M + bm - 1) / bm;
 }
 
 void launch_conv_gemm(const ConvGemmParams& p, int force, hipStream_t s) {
-  launch_by_id(pick_cfg(p.M, p.N, force), p, s);
+  const int bm = halo_bm(p, force);
+  if (bm) launch_conv3x3_halo(p, bm, s);
+  else launch_by_id(pick_cfg(p.M, p.N, force == 2000 ? 0 : force), p, s);
 }
 
 }  // namespace ddl

@@ -41,7 +41,9 @@ def test_conv1x1_fwd_prefix_prologue_stats(dev, M, C, N, Cf, bm):
     torch.testing.assert_close(st[:, 1].sum(0).double(), (ref * ref).sum(0), rtol=1e-4, atol=1e-2)
 
 
-@pytest.mark.parametrize("B,H,W,bm", [(2, 14, 14, 0), (3, 7, 7, 32), (1, 56, 56, 128), (5, 28, 28, 64)])
+# bm 2000 = the halo kernel (conv3x3_halo.hip) whatever the size; (12, 56, 56, 0) reaches it through the heuristic
+@pytest.mark.parametrize("B,H,W,bm", [(2, 14, 14, 0), (3, 7, 7, 32), (1, 56, 56, 128), (5, 28, 28, 64), (2, 14, 14, 2000),
+                                      (3, 7, 7, 2000), (1, 56, 56, 2000), (5, 28, 28, 2000), (12, 56, 56, 0), (1, 9, 5, 2000)])
 def test_conv3x3_fwd_slice_write(dev, B, H, W, bm):
     from ddl import ops
     from ddl.models.native_densenet import NativeDenseNetStage
@@ -58,6 +60,37 @@ def test_conv3x3_fwd_slice_write(dev, B, H, W, bm):
     torch.testing.assert_close(buf[:, 96:128].double(), ref, rtol=1e-4, atol=1e-4)
     assert buf[:, :96].abs().sum() == 0 and buf[:, 128:].abs().sum() == 0      # only the slice was written
     torch.testing.assert_close(st[:, 0].sum(0).double(), ref.sum(0), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("B,H,W,bm", [(2, 14, 14, 0), (3, 7, 7, 32), (5, 28, 28, 64), (2, 14, 14, 2000), (3, 7, 7, 2000),
+                                      (1, 56, 56, 2000), (5, 28, 28, 2000), (6, 56, 56, 0), (1, 9, 5, 2000)])
+def test_conv3x3_dgrad_mask_stats(dev, B, H, W, bm):
+    """3x3 data gradient: two-source prologue dy = d + q*x + p, transposed (k-major) weights, flipped taps, ReLU/BN
+    mask in the epilogue, (sum g, sum g*h) statistics - conv_gemm tiles and the halo kernel against fp64."""
+    from ddl import ops
+    from ddl.models.native_densenet import NativeDenseNetStage
+    ext = ops.require_ext()
+    M, C, N = B * H * W, 128, 32
+    h = _rand(M, C, dev=dev, seed=1)
+    sc, sh = _rand(C, dev=dev, seed=2).abs() + 0.5, _rand(C, dev=dev, seed=3)
+    w = _rand(N, C, 3, 3, dev=dev, seed=4, scale=0.05)
+    wn = NativeDenseNetStage._to_native(w)
+    dbuf, xbuf = _rand(M, 256, dev=dev, seed=5), _rand(M, 256, dev=dev, seed=6)
+    d, x = dbuf[:, 64:96], xbuf[:, 64:96]
+    q, pp = _rand(N, dev=dev, seed=7, scale=0.1), _rand(N, dev=dev, seed=8, scale=0.1)
+    ones = torch.ones(N, device=dev)
+    g2 = torch.full((M, C), float("nan"), device=dev)
+    st = ext.conv_gemm(d, x, ones, q, pp, False, M, H, W, 9, True, wn, True, g2, True, False, h, sc, sh, 2, bm)
+    dy64 = (d.double() + q.double() * x.double() + pp.double()).view(B, H, W, N).permute(0, 3, 1, 2)
+    gref = F.conv_transpose2d(dy64, w.double(), padding=1).permute(0, 2, 3, 1).reshape(M, C)
+    pre = h.double() * sc.double() + sh.double()
+    keep = pre > 0
+    unsure = pre.abs() < 1e-5                               # fp32 mask may differ from the fp64 one there
+    gref = torch.where(keep, gref, torch.zeros_like(gref))
+    diff = (g2.double() - gref).abs()
+    assert float(diff[~unsure].max()) < 2e-4
+    sref = torch.stack([g2.double().sum(0), (g2.double() * h.double()).sum(0)])
+    torch.testing.assert_close(st.sum(0).double(), sref, rtol=1e-4, atol=1e-3)
 
 
 @pytest.mark.parametrize("M,C,Cf,new0,taps,HW", [(3136, 96, 256, 64, 1, 56), (300, 64, 256, 64, 1, 0), (94, 992, 1024, 960, 1, 0),
