@@ -13,7 +13,7 @@ for f in sorted(glob.glob(os.path.join(root, "*_counter_collection.csv"))):
     case = os.path.basename(f).split("_SQ_")[0]
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if not any(s in k for s in ("conv_gemm_kernel", "wgrad1x1_kernel", "wgrad3x3_kernel")):
+        if not any(s in k for s in ("conv_gemm_kernel", "conv3x3_halo_kernel", "wgrad1x1_kernel", "wgrad3x3_kernel")):
             continue
         c = cases[case]
         c[r["Counter_Name"]] += float(r["Counter_Value"])

@@ -91,7 +91,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv3x3_halo_kernel(const ConvGe
     bits[i] = b;
   }
 
-  f32x4 a_v[PA], b_reg[PB];
+  // weights travel three taps ahead of their use (one tap of MFMAs is shorter than an L2 round trip):
+  // b_q[t % 3] holds tap t from its load until it is written to the LDS buffer one tap before its use
+  f32x4 a_v[PA], b_q[3][PB];
   auto load_a = [&](int chunk) {
     const unsigned dc = (unsigned)(chunk * 128);        // 32 channels * 4 bytes
 #pragma unroll
@@ -118,20 +120,20 @@ __global__ void __launch_bounds__(64 * WM * WN) conv3x3_halo_kernel(const ConvGe
       if (r < R) *reinterpret_cast<f32x4*>(As + r * LDA + 4 * cq) = v;
     }
   };
-  auto load_b = [&](int chunk, int tap) {              // weights [N][9][C], one tap, 32 channels
+  auto load_b = [&](int chunk, int tap, f32x4 (&dst)[PB]) {     // weights [N][9][C], one tap, 32 channels
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       const int f = tid + i * NT;
       const int n = n0 + (f >> 3);
       const unsigned off = (unsigned)((n * p.ldb + tap * p.C + chunk * 32 + 4 * (f & 7)) * 4);
-      b_reg[i] = bld4(rW, n < p.N ? off : OOB);
+      dst[i] = bld4(rW, n < p.N ? off : OOB);
     }
   };
-  auto store_b = [&](int buf) {
+  auto store_b = [&](int buf, const f32x4 (&src)[PB]) {
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       const int f = tid + i * NT;
-      *reinterpret_cast<f32x4*>(Bs + buf * B_ELEMS + (f >> 3) * LDA + 4 * (f & 7)) = b_reg[i];
+      *reinterpret_cast<f32x4*>(Bs + buf * B_ELEMS + (f >> 3) * LDA + 4 * (f & 7)) = src[i];
     }
   };
 
@@ -173,24 +175,26 @@ __global__ void __launch_bounds__(64 * WM * WN) conv3x3_halo_kernel(const ConvGe
     }
   };
 
-  // ---- main loop: chunk = 32 input channels; per chunk the range is staged once, then nine taps ------
+  // ---- main loop: chunk = 32 input channels; per chunk the range is staged once, then nine taps.
+  // Step s = chunk * 9 + tap reads weight buffer s & 1 = (chunk + tap) & 1.
   load_a(0);
-  load_b(0, 0);
+  load_b(0, 0, b_q[0]);
+  load_b(0, 1, b_q[1]);
+  load_b(0, 2, b_q[2]);
   conv_fill_tables<NT, 0>(p, affine, scs, shs, scs, tid);        // scale / shift tables (fused statistics)
   __syncthreads();
   store_a(0);
-  store_b(0);
+  store_b(0, b_q[0]);
   __syncthreads();
-  int step = 0;                                                   // chunk * 9 + tap
   for (int chunk = 0; chunk < chunks; ++chunk) {
     const bool more = chunk + 1 < chunks;
     if (more) load_a(chunk + 1);                                  // in flight under the nine taps
-#pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap, ++step) {
-      const bool next = tap < 8 || more;
-      if (next) load_b(tap < 8 ? chunk : chunk + 1, tap < 8 ? tap + 1 : 0);
-      compute(tap, step & 1);
-      if (next) store_b((step + 1) & 1);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      compute(tap, (chunk + tap) & 1);
+      if (tap < 8 || more) store_b((chunk + tap + 1) & 1, b_q[(tap + 1) % 3]);
+      if (tap + 3 < 9) load_b(chunk, tap + 3, b_q[tap % 3]);
+      else if (more) load_b(chunk + 1, tap + 3 - 9, b_q[tap % 3]);
       __syncthreads();
     }
     if (more) {
