@@ -349,7 +349,9 @@ def test_dense_block4_small_spatial(dev, fused):
 
 def test_dense_block_many_row_tiles(dev):
     """Enough row tiles that every statistics-accumulator replica takes atomics from several workgroups."""
-    _compare_unit(dev, ("denseblock1",), (6, 64, 56, 56), fused=(True, True))
+    # 113k pixels per channel: single ReLU pre-activations within fp32 rounding of zero flip between implementations
+    # (torch fp32 itself is 7e-4 off fp64 on some bias gradients here), so the gradient is judged as a whole
+    _compare_unit(dev, ("denseblock1",), (6, 64, 56, 56), fused=(True, True), global_l2=True)
 
 
 def test_transition_fwd_bwd(dev):
