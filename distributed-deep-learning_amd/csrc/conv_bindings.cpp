@@ -260,7 +260,7 @@ void conv_wgrad(const at::Tensor& d0, const OptT& d1, const OptT& ds0, const Opt
                   dW.numel() == N * taps * C && (reinterpret_cast<uintptr_t>(dW.data_ptr()) % 16) == 0,
               "dW must be a contiguous aligned [N, taps*C] float32 tensor");
   const int other = taps == 1 ? (int)(((C + 127) / 128) * ((N + 127) / 128)) : (int)(3 * ((C + 127) / 128));
-  p.rows_per_wg = ddl::wgrad_rows_per_wg((int)M, other, (int)min_rows);
+  p.rows_per_wg = ddl::wgrad_rows_per_wg((int)M, other, (int)min_rows, taps == 1 ? 512 : 768);
   p.S = (int)((M + p.rows_per_wg - 1) / p.rows_per_wg);
   auto slabs = at::empty({p.S, N, taps * C}, d0.options());
   p.slabs = slabs.data_ptr<float>();

@@ -368,8 +368,10 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
 
 // rows per workgroup (multiple of 32) for a weight-gradient launch: as many chunks as it takes
 // to fill the chip, but never so many that the slab traffic outweighs the operand traffic.
-int wgrad_rows_per_wg(int M, int other_grid, int min_rows) {
-  long want_chunks = (768 + other_grid - 1) / other_grid;
+// `target_wgs` = resident workgroup slots of the kernel (1x1: 64 KB LDS -> 2 per CU = 512; 3x3: 3 per CU =
+// 768), so the grid is one full round rather than one and a half (1x1 at 768: 79 -> 76 us, 44 -> 39 us).
+int wgrad_rows_per_wg(int M, int other_grid, int min_rows, int target_wgs) {
+  long want_chunks = (target_wgs + other_grid - 1) / other_grid;
   long rows = (M + want_chunks - 1) / want_chunks;
   if (rows < min_rows) rows = min_rows;
   rows = (rows + 31) / 32 * 32;

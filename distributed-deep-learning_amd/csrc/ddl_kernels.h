@@ -33,7 +33,7 @@ void launch_conv_gemm(const ConvGemmParams& p, int force_bm, hipStream_t s);
 int conv3x3_halo_bm(const ConvGemmParams& p, bool any_size);   // row-tile height if the halo kernel takes p, else 0
 void launch_conv3x3_halo(const ConvGemmParams& p, int bm, hipStream_t s);
 // ---- conv_wgrad.hip --------------------------------------------------------------------
-int wgrad_rows_per_wg(int M, int other_grid, int min_rows);
+int wgrad_rows_per_wg(int M, int other_grid, int min_rows, int target_wgs);
 void launch_wgrad(const WgradParams& p, float* dW, hipStream_t s);
 // ---- bn_kernels.hip --------------------------------------------------------------------
 void launch_bn_prep(const float* partials, int G, int ldp, int new0, int n_new, double count,
