@@ -218,8 +218,8 @@ void launch_halo(const ConvGemmParams& p, hipStream_t s) {
   if (sta > lds) lds = sta;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, WM, WN>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, WM, WN>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     attr_set = true;
   }
   dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.N + BN - 1) / BN));

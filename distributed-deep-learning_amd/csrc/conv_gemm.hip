@@ -54,7 +54,7 @@ namespace {
 // weights are transposed while being staged, so the MFMA loop is the same for every kind.
 template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF, int KIND, bool BF>
 __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const ConvGemmParams p) {
-  constexpr bool TWO = KIND >= 2, KMAJOR = KIND >= 1, EPM = KIND >= 2, EPA = KIND == 3;
+  constexpr bool TWO = KIND >= 2, KMAJOR = KIND >= 1;
   constexpr int LDH = 32 * KS + 8;       // bf16 image row stride (elements)
   constexpr int NT = 64 * WM * WN * KS;
   constexpr int TM = BM / (32 * WM);
@@ -400,8 +400,8 @@ void launch_inst(const ConvGemmParams& p, hipStream_t s) {
   const size_t lds = m1t > m2 ? m1t : m2;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, KS, NBUF, PF, KIND, BF>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, KS, NBUF, PF, KIND, BF>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     attr_set = true;
   }
   dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.N + BN - 1) / BN));

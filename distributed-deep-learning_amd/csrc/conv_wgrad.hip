@@ -383,14 +383,14 @@ void launch_wgrad(const WgradParams& p, float* dW, hipStream_t s) {
   const size_t lds1 = (size_t)4 * RK * 128 * sizeof(float);
   const size_t lds3 = (size_t)(2 * RK * 32 + 2 * (RK + 2) * 128 + 2 * RK) * sizeof(float);
   if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x1_kernel<false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x1_kernel<true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x1_kernel<false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x1_kernel<true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
     attr = true;
   }
   const bool two = p.d.X1 != nullptr;

@@ -4,6 +4,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <stdexcept>
+#include <string>
+
+// host-side HIP calls of the launchers (attribute set-up): fail loudly, pybind turns it into a RuntimeError
+#define DDL_HIP_CHECK(expr)                                                                              \
+  do {                                                                                                   \
+    const hipError_t ddl_err_ = (expr);                                                                  \
+    if (ddl_err_ != hipSuccess) throw std::runtime_error(std::string(#expr ": ") + hipGetErrorString(ddl_err_)); \
+  } while (0)
 
 namespace ddl {
 

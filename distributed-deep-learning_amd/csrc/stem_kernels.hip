@@ -520,8 +520,8 @@ void launch_stem_conv_fwd(const float* xp, const float* wp, float* y0, float* st
   constexpr size_t lds = (size_t)(2 * FBM * FLD + 2 * NC0 * FLD) * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv_fwd_kernel),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv_fwd_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
   const unsigned xp_bytes = (unsigned)((M0 / ((long)H0 * W0)) * H * W * 16);      // < 2 GiB: checked by the binding
