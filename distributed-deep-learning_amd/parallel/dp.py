@@ -102,6 +102,9 @@ class DataParallelEngine:
             if profiler is not None:
                 profiler.add_source("rccl", self._native.drain_ms)
 
+        # per-forward buffer broadcast behind the forward instead of in front of it (after_forward)
+        self._defer_buffers = (self.on_cuda and not self.single and not debug_sync
+                               and comm.backend_of(group) == "nccl")
         self.broadcast_state()
         if register_hooks:
             for i, p in enumerate(self.arena.params):
@@ -126,10 +129,33 @@ class DataParallelEngine:
         if include_int and self.buffers.flat_int.numel():
             comm.broadcast(self.buffers.flat_int, self.src_global, self.group)
 
-    def pre_forward(self) -> None:
-        """Call before a forward pass (train or eval): DDP's ``broadcast_buffers=True``."""
-        if self.sync_buffers_policy == "forward":
-            self._timed(self.broadcast_buffers)
+    def pre_forward(self, training: bool = False) -> None:
+        """Call before a forward pass (train or eval): DDP's ``broadcast_buffers=True``.
+        Training steps on RCCL defer it to ``after_forward`` (same values, off the critical path)."""
+        if self.sync_buffers_policy != "forward" or (training and self._defer_buffers):
+            return
+        self._timed(self.broadcast_buffers)
+
+    def after_forward(self) -> None:
+        """Training step, policy ``forward``: BN buffers only change in the forward pass, so "rank 0's buffers
+        before forward k+1" (what DDP broadcasts) are final as soon as forward k is done.  They travel on the
+        communication stream while backward k runs; the grads-ready fence of ``finish_grad_sync`` covers them,
+        so the next forward (or an evaluation / checkpoint in between) sees synchronised buffers - without a
+        blocking broadcast in front of every step."""
+        if self.sync_buffers_policy != "forward" or not self._defer_buffers:
+            return
+        main = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ready)
+            tok = self.profiler.begin("rccl", self.comm_stream) if self.profiler else None
+            self.broadcast_buffers()
+            if tok is not None:
+                self.profiler.end(tok, self.comm_stream)
+            done = torch.cuda.Event()
+            done.record(self.comm_stream)
+        self._done_events.append(done)
 
     def epoch_boundary(self) -> None:
         if self.sync_buffers_policy == "epoch":
@@ -238,6 +264,10 @@ class DataParallelEngine:
         (segments whose hooks did not all fire, e.g. unused parameters)."""
         if self._native is not None:
             self._native.finish()
+            main = torch.cuda.current_stream(self.device)
+            for ev in self._done_events:           # deferred buffer broadcast (after_forward)
+                main.wait_event(ev)
+            self._done_events.clear()
             return
         if self._armed:
             for k in range(len(self.arena.segments)):

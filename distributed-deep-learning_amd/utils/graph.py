@@ -48,9 +48,11 @@ class GraphedTrainStep:
         self._pool = None
 
     # ---- the step body ----------------------------------------------------------------------
-    def _fwd_bwd(self, x, y):
+    def _fwd_bwd(self, x, y, after_forward=None):
         self.optimizer.zero_grad()
         out = self.model(x)
+        if after_forward is not None:
+            after_forward()
         loss, preds = ops.cross_entropy_with_preds(out, y)
         loss.backward()
         return loss.detach(), out.detach(), preds
@@ -58,9 +60,9 @@ class GraphedTrainStep:
     def _eager(self, x, y):
         dp, prof = self.dp, self.profiler
         if dp is not None:
-            dp.pre_forward()
+            dp.pre_forward(training=True)
             dp.arm(True)
-        res = self._fwd_bwd(x, y)
+        res = self._fwd_bwd(x, y, dp.after_forward if dp is not None else None)
         if dp is not None:
             tok = prof.begin("exposed_comm") if prof else None
             dp.finish_grad_sync()
@@ -128,10 +130,12 @@ class GraphedTrainStep:
         c.x.copy_(x, non_blocking=True)
         c.y.copy_(y, non_blocking=True)
         if dp is not None:
-            dp.pre_forward()
+            dp.pre_forward(training=True)
         if self.distributed:
             dp.arm(True)
         c.graph.replay()
+        if dp is not None:
+            dp.after_forward()                 # graph 0 holds the whole forward: buffers are final behind it
         for i, g in enumerate(c.tail_graphs):
             for k in c.phase_segments[i]:      # buckets completed by the graph just enqueued
                 dp.segment_ready(k)
