@@ -103,3 +103,25 @@ def test_mesh_smoke_and_split_explorer(tmp_path):
     assert "all_reduce over pp group -> 1" in out and "all_reduce over pp group -> 5" in out
     out = _run([sys.executable, "debug.py"], _env(tmp_path))
     assert "Model parameters: 7978856" in out and "Total num params: 7978856" in out
+
+
+def test_bench_json_contract_cpu(tmp_path):
+    """bench.py prints ONE JSON line with the driver's fields; on CPU it runs the PyTorch stage over gloo (world 2)."""
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), "bench.py", "--gpus", "2",
+                        "--steps", "1", "--warmup", "0", "--batch-per-gpu", "2"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config"):
+        assert k in rec, k
+    assert rec["n_gpus"] == 2 and rec["steps"] == 1 and rec["warmup"] == 0 and rec["unit"] == "samples/s"
+    assert rec["higher_is_better"] is True and rec["scaling"] == "weak" and rec["dtype"] == "fp32"
+    assert rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2"
+    assert rec["value"] == pytest.approx(4 * 1 / (rec["ms_per_step"] / 1e3), rel=1e-3)
+    assert "profile" in rec and rec["profile"]["steps"] == 1
