@@ -27,6 +27,7 @@ namespace ddl {
 namespace {
 
 constexpr int HALO_MAXW = 56;            // widest feature map of DenseNet-121 after the stem
+constexpr int kMaxSmallC = 128;          // small-M form: channels of the staged range (the dense layers' bottleneck width)
 
 template <int BM, int BN, int WM, int WN>
 __global__ void __launch_bounds__(64 * WM * WN) conv3x3_halo_kernel(const ConvGemmParams p) {
@@ -205,6 +206,173 @@ __global__ void __launch_bounds__(64 * WM * WN) conv3x3_halo_kernel(const ConvGe
   conv_epilogue<BM, BN, WM, WN, NT, 0>(p, acc, smem, m0, n0, tile_x, tid, 0, wmn);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small-M form (14x14 / 7x7 maps, and 28x28 at small batch): fewer row tiles than CUs, so the kernel is
+// bound by its chain of dependent phases, not by throughput.  conv_gemm's K-split tiles run
+// ceil(36 / KS) slab iterations of load -> LDS -> barrier -> MFMA.  Here the whole input range (all C
+// channels, halo rows included) is staged with ONE round of loads and one barrier; after that every
+// wave works alone: wave (row block, k group) takes every KS-th (chunk, tap) pair, pulls the 32x32 weight
+// block of the pair straight from L2 into registers (it is an MFMA operand as loaded: lane (n, h) holds
+// channels 16h..16h+15 of output channel n) and reads its input rows from LDS at the tap's row offset.
+// No barrier until the K-split combine.  The k-steps of a pair are ordered c = 16h + s for both operands.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int KS>
+__global__ void __launch_bounds__(64 * (BM / 32) * KS) conv3x3_small_kernel(const ConvGemmParams p) {
+  constexpr int WM = BM / 32, NT = 64 * WM * KS;
+  constexpr int MAXW = 28;
+  constexpr int RMAX = BM + 2 * MAXW + 2;
+  constexpr int MAXQ = kMaxSmallC / 4;                 // float4 per staged row
+  constexpr int PA = (RMAX * MAXQ + NT - 1) / NT;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const bool affine = p.a.s0 != nullptr || p.bn.acc != nullptr;
+  const int lda = p.C + 4;                             // staged row stride (floats)
+  const int halo = p.W + 1;
+  const int R = BM + 2 * halo;
+  float* scs = smem;
+  float* shs = smem + p.C;
+  float* As = smem + (affine ? 2 * p.C : 0);           // [R][lda]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int ks = wid / WM, wm = wid - ks * WM;
+  const int li = lane & 31, lh = lane >> 5;
+  int tile_x;
+  {   // XCD-aware tile order (see conv_gemm.hip)
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    tile_x = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int m0 = tile_x * BM;
+  const int n0 = blockIdx.y * 32;
+  const int chunks = p.C >> 5;
+  const int npairs = chunks * 9;
+  const int qrow = p.C >> 2;                           // float4 per row
+
+  const rsrc_t rA = make_rsrc(p.a.X0, p.a.bytes0);
+  const rsrc_t rW = make_rsrc(p.Wt, p.wbytes);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // ---- one round of loads for the whole range ---------------------------------------------------
+  f32x4 a_v[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int f = tid + i * NT;
+    const int r = f / qrow, cq = f - r * qrow;
+    const int m = m0 - halo + r;
+    const bool ok = r < R && m >= 0 && m < p.M;
+    a_v[i] = bld4(rA, ok ? (unsigned)m * (unsigned)(p.a.ld0 * 4) + (unsigned)(16 * cq) : OOB);
+  }
+  // this lane's 9-bit tap mask (its pixel is row li of row block wm)
+  unsigned bits = 0;
+  {
+    const int m = m0 + wm * 32 + li;
+    if (m < p.M) {
+      const int rem = m % (p.H * p.W);
+      const int y = rem / p.W, x = rem - y * p.W;
+      const unsigned yb = (y > 0) | 2u | ((unsigned)(y < p.H - 1) << 2);
+      const unsigned xb = (x > 0) | 2u | ((unsigned)(x < p.W - 1) << 2);
+      bits = ((yb & 1u) ? xb : 0u) | ((yb & 2u) ? (xb << 3) : 0u) | ((yb & 4u) ? (xb << 6) : 0u);
+    }
+  }
+  // weight block of a pair: lane (n = li, h = lh) loads channels [16h, 16h + 16) of output channel n0 + li
+  const unsigned w_row = (unsigned)((n0 + li) * p.ldb * 4 + 64 * lh);
+  const bool w_ok = n0 + li < p.N;
+  auto load_w = [&](int pair, f32x4 (&w)[4]) {
+    const int chunk = pair / 9, tap = pair - 9 * chunk;
+    const unsigned off = w_row + (unsigned)((tap * p.C + chunk * 32) * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = bld4(rW, (w_ok && pair < npairs) ? off + 16u * q : OOB);
+  };
+  f32x4 w0[4], w1[4];
+  load_w(ks, w0);
+  load_w(ks + KS, w1);
+
+  conv_fill_tables<NT, 0>(p, affine, scs, shs, scs, tid);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int f = tid + i * NT;
+    const int r = f / qrow, cq = f - r * qrow;
+    f32x4 v = a_v[i];
+    if (affine) {
+      v = ld4(scs + 4 * cq) * v + ld4(shs + 4 * cq);
+      if (p.a.relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+    }
+    if (r < R) *reinterpret_cast<f32x4*>(As + r * lda + 4 * cq) = v;      // out-of-tensor rows: masked by `bits`
+  }
+  __syncthreads();
+
+  // ---- every wave on its own: pairs ks, ks + KS, ... ---------------------------------------------
+  f32x16 acc[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+  auto pair_mfma = [&](int pair, const f32x4 (&w)[4]) {
+    const int chunk = pair / 9, tap = pair - 9 * chunk;
+    const int ty = (tap * 11) >> 5, tx = tap - 3 * ty;
+    const float* Ab = As + (halo + (ty - 1) * p.W + (tx - 1) + wm * 32 + li) * lda + chunk * 32 + 16 * lh;
+    const bool on = (bits >> tap) & 1u;
+    f32x4 a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a[q] = ld4(Ab + 4 * q);
+      a[q] = on ? a[q] : zero4;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], w[q][e], acc[0][0], 0, 0, 0);
+  };
+  for (int pair = ks; pair < npairs; pair += 2 * KS) {       // weights two pairs ahead of their use
+    pair_mfma(pair, w0);
+    load_w(pair + 2 * KS, w0);
+    if (pair + KS < npairs) pair_mfma(pair + KS, w1);
+    load_w(pair + 3 * KS, w1);
+  }
+  __syncthreads();                                            // the staged range is dead: combine over ks
+
+  if (KS > 1) {
+    float* red = smem;                                        // [KS-1][WM][16][64]
+    if (ks > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(((ks - 1) * WM + wm) * 16 + r) * 64 + lane] = acc[0][0][r];
+    }
+    __syncthreads();
+    if (ks == 0) {
+#pragma unroll
+      for (int k2 = 1; k2 < KS; ++k2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += red[(((k2 - 1) * WM + wm) * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  conv_epilogue<BM, 32, WM, 1, NT, 0>(p, acc, smem, m0, n0, tile_x, tid, ks, wm);
+}
+
+template <int BM, int KS>
+void launch_small(const ConvGemmParams& p, hipStream_t s) {
+  constexpr int WM = BM / 32, NT = 64 * WM * KS;
+  constexpr size_t red = (size_t)(KS - 1) * WM * 16 * 64 * sizeof(float);
+  constexpr size_t epi = (size_t)WM * 32 * 36 * sizeof(float);
+  constexpr size_t sta = (size_t)2 * WM * 8 * 32 * sizeof(float);
+  constexpr size_t lds_max = ((size_t)(BM + 2 * 28 + 2) * (kMaxSmallC + 4) + 2 * kMaxSmallC) * sizeof(float);
+  const bool tables = p.a.s0 != nullptr || p.bn.acc != nullptr;
+  size_t lds = ((tables ? (size_t)2 * p.C : 0) + (size_t)(BM + 2 * p.W + 2) * (p.C + 4)) * sizeof(float);
+  if (red > lds) lds = red;
+  if (epi > lds) lds = epi;
+  if (sta > lds) lds = sta;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_small_kernel<BM, KS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.N + 31) / 32));
+  hipLaunchKernelGGL((conv3x3_small_kernel<BM, KS>), grid, dim3(NT), lds, s, p);
+}
+
 template <int BM, int BN, int WM, int WN>
 void launch_halo(const ConvGemmParams& p, hipStream_t s) {
   constexpr int NT = 64 * WM * WN;
@@ -228,19 +396,24 @@ void launch_halo(const ConvGemmParams& p, hipStream_t s) {
 
 }  // namespace
 
-// Which problems take this kernel: fp32 forward 3x3 with N <= 32, feature maps up to 56 wide and - unless
-// `any_size` (tests) - enough 128-row tiles to fill the chip; the small-M layers keep conv_gemm's K-split tiles
-// (64-row halo tiles are two waves per workgroup: 51 vs 31 us on block 2 at batch 30).
-// Returns the row-tile height (0: not eligible).
-int conv3x3_halo_bm(const ConvGemmParams& p, bool any_size) {
-  if (p.taps != 9 || p.kind != 0 || p.bf16 || p.W > HALO_MAXW || p.W < 1 || (p.C & 31)) return 0;
-  if (p.N > 32 || p.C > kMaxAffineC) return 0;
-  return ((p.M + 127) / 128 >= 384 || any_size) ? 128 : 0;
+// Which problems take these kernels: fp32 forward 3x3 with N <= 32.  Returns the row-tile height, 0 = not
+// eligible (conv_gemm's tiles), and selects the form through `form`:
+//   big   (128 rows, maps up to 56 wide): at least 384 row tiles - or `any_size` (tests, force 2000)
+//   small (32 rows, maps up to 28 wide, C <= 128): fewer row tiles than that - or force 2001
+int conv3x3_halo_bm(const ConvGemmParams& p, int force) {
+  if (p.taps != 9 || p.kind != 0 || p.bf16 || p.W < 1 || (p.C & 31) || p.N > 32) return 0;
+  const bool big_ok = p.W <= HALO_MAXW && p.C <= kMaxAffineC;
+  const bool small_ok = p.W <= 28 && p.C <= kMaxSmallC;
+  if (force == 2000) return big_ok ? 128 : 0;
+  if (force == 2001) return small_ok ? 32 : 0;
+  if (force != 0) return 0;
+  if (big_ok && (p.M + 127) / 128 >= 384) return 128;
+  return small_ok ? 32 : 0;
 }
 
 void launch_conv3x3_halo(const ConvGemmParams& p, int bm, hipStream_t s) {
-  (void)bm;
-  launch_halo<128, 32, 4, 1>(p, s);
+  if (bm == 128) launch_halo<128, 32, 4, 1>(p, s);
+  else launch_small<32, 8>(p, s);
 }
 
 }  // namespace ddl

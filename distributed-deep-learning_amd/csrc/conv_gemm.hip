@@ -503,24 +503,24 @@ int pick_cfg(const ConvGemmParams& p, int force) {
 
 }  // namespace
 
-// `force` == 2000 sends an eligible 3x3 problem to the halo kernel whatever its size, any other non-zero
-// value keeps it on the conv_gemm tiles (tests / bench/kernel_bench.py); DDL_HALO=0 disables the halo kernel.
+// `force` == 2000 / 2001 sends an eligible 3x3 problem to the big / small halo kernel whatever its size, any other
+// non-zero value keeps it on the conv_gemm tiles (tests / bench/kernel_bench.py); DDL_HALO=0 disables both.
 static int halo_bm(const ConvGemmParams& p, int force) {
   static const bool enabled = [] { const char* e = getenv("DDL_HALO"); return !(e && e[0] == '0'); }();
-  if (!enabled || (force != 0 && force != 2000)) return 0;
-  return conv3x3_halo_bm(p, force == 2000);
+  if (!enabled) return 0;
+  return conv3x3_halo_bm(p, force);
 }
 
 int conv_gemm_grid_x(const ConvGemmParams& p, int force) {
   int bm = halo_bm(p, force);
-  if (!bm) bm = kCfg[pick_cfg(p, force == 2000 ? 0 : force)].bm;
+  if (!bm) bm = kCfg[pick_cfg(p, force >= 2000 ? 0 : force)].bm;
   return (p.M + bm - 1) / bm;
 }
 
 void launch_conv_gemm(const ConvGemmParams& p, int force, hipStream_t s) {
   const int bm = halo_bm(p, force);
   if (bm) launch_conv3x3_halo(p, bm, s);
-  else launch_by_id(pick_cfg(p, force == 2000 ? 0 : force), p, s);
+  else launch_by_id(pick_cfg(p, force >= 2000 ? 0 : force), p, s);
 }
 
 }  // namespace ddl

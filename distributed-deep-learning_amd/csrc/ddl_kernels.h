@@ -39,7 +39,7 @@ namespace ddl {
 int conv_gemm_grid_x(const ConvGemmParams& p, int force_bm);   // number of row tiles (= rows of the stats table)
 void launch_conv_gemm(const ConvGemmParams& p, int force_bm, hipStream_t s);
 // ---- conv3x3_halo.hip ------------------------------------------------------------------
-int conv3x3_halo_bm(const ConvGemmParams& p, bool any_size);   // row-tile height if the halo kernel takes p, else 0
+int conv3x3_halo_bm(const ConvGemmParams& p, int force);       // row-tile height if a halo kernel takes p, else 0
 void launch_conv3x3_halo(const ConvGemmParams& p, int bm, hipStream_t s);
 // ---- conv_wgrad.hip --------------------------------------------------------------------
 int wgrad_rows_per_wg(int M, int other_grid, int min_rows, int target_wgs);

@@ -41,9 +41,12 @@ def test_conv1x1_fwd_prefix_prologue_stats(dev, M, C, N, Cf, bm):
     torch.testing.assert_close(st[:, 1].sum(0).double(), (ref * ref).sum(0), rtol=1e-4, atol=1e-2)
 
 
-# bm 2000 = the halo kernel (conv3x3_halo.hip) whatever the size; (12, 56, 56, 0) reaches it through the heuristic
+# bm 2000 / 2001 = the big / small halo kernel (conv3x3_halo.hip) whatever the size; 0 = heuristic: (12, 56, 56) takes
+# the big form, the 28 / 14 / 7 wide maps the small one; 32 / 64 / 128 keep the conv_gemm tiles
 @pytest.mark.parametrize("B,H,W,bm", [(2, 14, 14, 0), (3, 7, 7, 32), (1, 56, 56, 128), (5, 28, 28, 64), (2, 14, 14, 2000),
-                                      (3, 7, 7, 2000), (1, 56, 56, 2000), (5, 28, 28, 2000), (12, 56, 56, 0), (1, 9, 5, 2000)])
+                                      (3, 7, 7, 2000), (1, 56, 56, 2000), (5, 28, 28, 2000), (12, 56, 56, 0), (1, 9, 5, 2000),
+                                      (2, 14, 14, 2001), (3, 7, 7, 0), (5, 28, 28, 2001), (1, 9, 5, 2001), (30, 14, 14, 0),
+                                      (2, 14, 14, 128)])
 def test_conv3x3_fwd_slice_write(dev, B, H, W, bm):
     from ddl import ops
     from ddl.models.native_densenet import NativeDenseNetStage
