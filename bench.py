@@ -42,6 +42,8 @@ def main() -> None:
     ap.add_argument("--pp-size", type=int, default=2)
     ap.add_argument("--bucket-mb", type=float, default=8.0)
     ap.add_argument("--zero1", action="store_true")
+    ap.add_argument("--grad-phases", default=None, help="units that open a new backward graph phase (DP overlap); "
+                    "default = TrainConfig's, '' = one graph + all collectives behind it")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--backend", default="auto", help="auto = RCCL; gloo lets several ranks share one GPU (rehearsal only)")
     ap.add_argument("--profile", action="store_true", help="add the compute/RCCL breakdown to the JSON")
@@ -69,7 +71,8 @@ def main() -> None:
                           bucket_mb=a.bucket_mb, zero1=a.zero1, hip_graph=hip_graph,
                           num_microbatches=a.microbatches, schedule=a.schedule, pp_size=pp_size,
                           split_points=default_split_points(max(pp_size, 1)), profile=a.profile,
-                          sync_buffers="forward", num_workers=0)
+                          sync_buffers="forward", num_workers=0,
+                          **({} if a.grad_phases is None else {"grad_phases": a.grad_phases}))
         return build_strategy(cfg, ctx)
 
     strat = make_strategy(not a.no_graph)
