@@ -137,6 +137,7 @@ class BucketReducer {
     return ms;
   }
 
+  void set_timing(bool on) { timing_ = on; }          // RCCL span events on / off (StepProfiler.set_enabled)
   int64_t launches() const { return launches_; }
 
  private:
@@ -175,5 +176,6 @@ void register_reducer(pybind11::module_& m) {
       .def("segment_ready", &BucketReducer::segment_ready)
       .def("finish", &BucketReducer::finish)
       .def("drain_ms", &BucketReducer::drain_ms)
+      .def("set_timing", &BucketReducer::set_timing)
       .def_property_readonly("launches", &BucketReducer::launches);
 }

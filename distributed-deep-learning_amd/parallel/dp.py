@@ -100,7 +100,7 @@ class DataParallelEngine:
                 grad_sync == "allreduce", bool(debug_sync), bool(profiler is not None and profiler.enabled),
                 cs.stream_id, cs.device_index, cs.device_type)
             if profiler is not None:
-                profiler.add_source("rccl", self._native.drain_ms)
+                profiler.add_source("rccl", self._native.drain_ms, self._native.set_timing)
 
         # per-forward buffer broadcast behind the forward instead of in front of it (after_forward)
         self._defer_buffers = (self.on_cuda and not self.single and not debug_sync

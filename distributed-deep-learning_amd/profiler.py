@@ -37,11 +37,23 @@ class StepProfiler:
         self.counts: Dict[str, int] = defaultdict(int)
         self.steps = 0
         self._sources: List[Tuple[str, object]] = []             # (name, fn() -> ms since the last call)
+        self._switches: List[object] = []
 
-    def add_source(self, name: str, fn) -> None:
-        """A span total measured elsewhere (the native bucket reducer times its RCCL calls itself)."""
+    def add_source(self, name: str, fn, set_enabled=None) -> None:
+        """A span total measured elsewhere (the native bucket reducer times its RCCL calls itself);
+        ``set_enabled(bool)`` switches that measurement together with this profiler."""
         if self.enabled:
             self._sources.append((name, fn))
+            if set_enabled is not None:
+                self._switches.append(set_enabled)
+
+    def set_enabled(self, on: bool) -> None:
+        """Pause / resume span recording (bench.py times its steps with the profiler paused and
+        measures the compute / RCCL split on extra steps afterwards)."""
+        self.collect()
+        self.enabled = on
+        for sw in self._switches:
+            sw(on)
 
     # ---- spans -----------------------------------------------------------------------
     def begin(self, name: str, stream=None):
@@ -77,7 +89,8 @@ class StepProfiler:
         return _Span()
 
     def step_done(self) -> None:
-        self.steps += 1
+        if self.enabled:
+            self.steps += 1
 
     # ---- results ---------------------------------------------------------------------
     def collect(self) -> None:

@@ -23,6 +23,12 @@ def test_profiler_spans_sources_and_fractions():
     s = prof.summary()
     assert s["steps"] == 4 and s["rccl_ms_per_step"] == pytest.approx(0.5)
     assert 0.0 <= s["comm_exposed_fraction"] <= 1.0 and s["compute_fraction"] == pytest.approx(1.0 - s["comm_exposed_fraction"])
+    prof.set_enabled(False)                        # paused: nothing is recorded or counted
+    tok = prof.begin("step")
+    prof.end(tok)
+    prof.step_done()
+    assert tok is None and prof.summary()["steps"] == 4
+    prof.set_enabled(True)
     prof.reset()
     assert prof.summary()["steps"] == 0 and "rccl_ms_per_step" not in prof.summary()
     off = StepProfiler("cpu", enabled=False)
