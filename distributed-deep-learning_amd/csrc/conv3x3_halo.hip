@@ -355,7 +355,7 @@ template <int BM, int KS>
 void launch_small(const ConvGemmParams& p, hipStream_t s) {
   constexpr int WM = BM / 32, NT = 64 * WM * KS;
   constexpr size_t red = (size_t)(KS - 1) * WM * 16 * 64 * sizeof(float);
-  constexpr size_t epi = (size_t)WM * 32 * 36 * sizeof(float);
+  constexpr size_t epi = (size_t)WM * 32 * kEpiLd * sizeof(float);
   constexpr size_t sta = (size_t)2 * WM * 8 * 32 * sizeof(float);
   constexpr size_t lds_max = ((size_t)(BM + 2 * 28 + 2) * (kMaxSmallC + 4) + 2 * kMaxSmallC) * sizeof(float);
   const bool tables = p.a.s0 != nullptr || p.bn.acc != nullptr;
@@ -377,7 +377,7 @@ template <int BM, int BN, int WM, int WN>
 void launch_halo(const ConvGemmParams& p, hipStream_t s) {
   constexpr int NT = 64 * WM * WN;
   constexpr size_t b_elems = (size_t)BN * 36;
-  constexpr size_t epi = (size_t)WM * WN * 32 * 36 * sizeof(float);
+  constexpr size_t epi = (size_t)WM * WN * 32 * kEpiLd * sizeof(float);
   constexpr size_t sta = (size_t)2 * WM * 8 * BN * sizeof(float);
   constexpr size_t lds_max = ((size_t)(BM + 2 * HALO_MAXW + 2) * 36 + 2 * b_elems + 2 * kMaxAffineC) * sizeof(float);
   const bool tables = p.a.s0 != nullptr || p.bn.acc != nullptr;

@@ -85,7 +85,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16 (&
   // a lane owns 4 consecutive columns of 4 rows: 4 dwordx4 loads / stores per tile and operand.
   // Rows >= M and columns >= N fall outside the descriptors (loads give 0, stores are dropped) and
   // their accumulators are exactly 0 (zeroed operand rows / weight columns): no per-element predicates.
-  constexpr int TLD = 36;                  // transposition image row stride (floats)
+  constexpr int TLD = kEpiLd;              // transposition image row stride (floats)
   f32x4 st1[TN], st2[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) { st1[j] = zero4; st2[j] = zero4; }

@@ -388,7 +388,7 @@ void launch_inst(const ConvGemmParams& p, hipStream_t s) {
   constexpr size_t stage = (NBUF * (size_t)BM * (BKT + 4) + NBUF * b_elems) * sizeof(float);
   // the K-split combine and the statistics reduce reuse the staging area
   constexpr size_t red = (size_t)(KS - 1) * (BM / 32) * (BN / 32) * 16 * 64 * sizeof(float);
-  constexpr size_t epi = (size_t)WM * WN * 32 * 36 * sizeof(float);      // epilogue transposition images
+  constexpr size_t epi = (size_t)WM * WN * 32 * kEpiLd * sizeof(float);      // epilogue transposition images
   constexpr size_t sta = (size_t)2 * WM * 8 * BN * sizeof(float);        // statistics combine
   constexpr size_t m1 = stage > red ? stage : red, m2 = epi > sta ? epi : sta;
   constexpr size_t lds_max = (m1 > m2 ? m1 : m2) + ((KIND == 0 || KIND == 3) ? kMaxAffineC * 3 * sizeof(float) : 0);

@@ -39,6 +39,9 @@ struct RowSrc {
 // that are added are fp32 sums of <= 128 rows, so the fixed-point rounding is below their own rounding.
 constexpr double kStatScale = 268435456.0;      // 2^28: fixed-point scale of the accumulators
 constexpr int kStatReplicas = 8;
+// epilogue transposition image: row stride in floats (rocprofv3: 5-10 % of the LDS-active cycles are bank
+// conflicts at 36, 18 % at 40; kernel times are the same either way)
+constexpr int kEpiLd = 36;
 constexpr int kMaxAffineC = 1024;               // forward BN prologue: scale / shift of <= 1024 channels staged in LDS
 struct FusedBn {
   const long long* acc;     // in: [R][2][acc_ld] sum / sum of squares of the row source's channels (nullptr: off)
