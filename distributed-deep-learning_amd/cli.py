@@ -32,7 +32,21 @@ def run_training(script: str, argv: Optional[List[str]] = None) -> Trainer:
     train_loader, test_loader = build_loaders(cfg, dp_rank=strategy.dp_rank, dp_size=strategy.dp_size,
                                               device=ctx.device, needs_input=strategy.needs_input)
     trainer = Trainer(strategy, train_loader, test_loader, cfg)
-    trainer.train(cfg.epochs)
+    try:
+        trainer.train(cfg.epochs)
+    except BaseException as e:      # noqa: BLE001
+        if not comm.is_dist() or isinstance(e, KeyboardInterrupt):
+            raise
+        # Failure path (the reference has none): a rank that dies inside the loop must not wait for
+        # its peers in barrier / destroy_process_group - they are blocked in a collective it will never join.
+        # Report, leave with a non-zero status at once; the launcher (torchrun / torchx) tears the job down, the
+        # process-group timeout (--timeout-s) covers a peer that hangs instead of dying, and --resume-latest
+        # restarts from the last complete snapshot.
+        import traceback
+        traceback.print_exc()
+        print(f"[GPU{ctx.rank}] fatal: {type(e).__name__}: {e} - aborting the job", file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(1)
     if comm.is_dist():
         comm.barrier()
         comm.destroy()

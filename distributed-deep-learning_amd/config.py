@@ -87,6 +87,7 @@ class TrainConfig:
     profile: bool = False               # per-step compute vs communication breakdown
     debug_sync: bool = False            # serialise comm streams (race hunting)
     check_collectives: bool = False     # collective-order checker (hash all-gather per step)
+    fault_inject: str = ""              # "rank:epoch:step" - raise there (failure-path tests: abort + --resume-latest)
 
     def replace(self, **kw: Any) -> "TrainConfig":
         return dataclasses.replace(self, **kw)

@@ -316,6 +316,7 @@ class Trainer:
         self.history: List[dict] = []
         self.last_epoch_time = 0.0
         self.samples_per_sec = 0.0
+        self._fault = tuple(int(v) for v in cfg.fault_inject.split(":")) if cfg.fault_inject else None
 
         snap_job, snap_epoch = cfg.snapshot_job_id, cfg.snapshot_epoch
         if cfg.resume_latest and snap_job is None:
@@ -365,6 +366,8 @@ class Trainer:
                                                           s.needs_target)):
             if step >= steps:
                 break
+            if self._fault == (s.global_rank, epoch, step):
+                raise RuntimeError(f"injected fault on rank {s.global_rank} at epoch {epoch} step {step} (--fault-inject)")
             res = s.train_step(x, y, n)
             if res is not None:
                 loss, _out, preds = res

@@ -125,3 +125,22 @@ def test_bench_json_contract_cpu(tmp_path):
     assert rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2"
     assert rec["value"] == pytest.approx(4 * 1 / (rec["ms_per_step"] / 1e3), rel=1e-3)
     assert "profile" in rec and rec["profile"]["profile_steps"] == 1 and rec["profile"]["step_ms_per_step"] > 0
+
+
+def test_rank_failure_aborts_job_and_resume_latest_recovers(tmp_path):
+    """Failure path (absent in the reference): a rank that dies mid-epoch takes the job down promptly
+    with a non-zero status instead of leaving its peer blocked in a collective; --resume-latest then restarts from
+    the last complete snapshot."""
+    import time
+    env = _env(tmp_path)
+    args = [*SMALL[2:], "--epochs", "3", "--batch-size", "8", "--save-every", "1"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), "ddp.py", *args, "--fault-inject", "1:1:1"]
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=420)
+    assert r.returncode != 0 and time.time() - t0 < 300
+    assert "injected fault on rank 1 at epoch 1 step 1" in r.stdout and "aborting the job" in r.stdout
+    assert "Epoch 0 | Saved snapshot" in r.stdout and "Epoch 1 | Saved snapshot" not in r.stdout
+    out = _torchrun(2, "ddp.py", [*args, "--resume-latest"], env)
+    assert "Resuming training from snapshot at Epoch 1" in out and "Starting Epoch 0" not in out
+    assert "Epoch 2 | Saved snapshot" in out
