@@ -285,6 +285,18 @@ class PPStrategy(Strategy):
 
 
 def build_strategy(cfg: TrainConfig, ctx: comm.CommContext) -> Strategy:
+    if cfg.debug_sync:
+        # race hunting: ONE stream for everything - eager launches (a captured graph would keep its
+        # forked branches), collectives on the compute stream, weight gradients in line.  The native engine is
+        # bit-deterministic, so a run that differs from the overlapped one points at a missing fence.
+        cfg = cfg.replace(hip_graph=False)
+    strat = _build_strategy(cfg, ctx)
+    if cfg.debug_sync and hasattr(strat.model, "overlap_wgrad"):
+        strat.model.overlap_wgrad = False
+    return strat
+
+
+def _build_strategy(cfg: TrainConfig, ctx: comm.CommContext) -> Strategy:
     if cfg.strategy == "single":
         return SingleStrategy(cfg, ctx)
     if cfg.strategy == "ddp":

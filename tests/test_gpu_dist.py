@@ -232,3 +232,22 @@ def test_native_reducer_matches_python_reducer(tmp_path):
         assert m, out[-2000:]
         losses.append(float(m.group(1)))
     assert losses[0] == losses[1], losses
+
+
+@pytest.mark.gpu
+def test_debug_sync_matches_overlapped_run(tmp_path):
+    """--debug-sync (one stream: eager launches, collectives on the compute stream, weight gradients in line) against
+    the default overlapped run (phased hipGraphs, side-stream weight gradients, comm stream, deferred buffer
+    broadcast): the engine is bit-deterministic, so the epoch loss must be identical - a missing fence would show."""
+    import re
+    losses = []
+    for extra in ([], ["--debug-sync"]):
+        os.environ["DDL_FORCE_COLLECTIVES"] = "1"
+        try:
+            out = _torchrun(1, "ddp.py", [*SMALL, "--max-steps", "6", "--batch-size", "8", "--seed", "11", *extra], tmp_path)
+        finally:
+            os.environ.pop("DDL_FORCE_COLLECTIVES", None)
+        m = re.search(r"Epoch 0 \| Loss: ([0-9.eE+-]+)", out)
+        assert m, out[-2000:]
+        losses.append(float(m.group(1)))
+    assert losses[0] == losses[1], losses
