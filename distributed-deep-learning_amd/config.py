@@ -87,6 +87,10 @@ class TrainConfig:
     profile: bool = False               # per-step compute vs communication breakdown
     debug_sync: bool = False            # serialise comm streams (race hunting)
     check_collectives: bool = False     # collective-order checker (hash all-gather per step)
+    trace_dir: Optional[str] = field(default_factory=lambda: os.environ.get("DDL_TRACE_DIR") or None)
+    #   ^ torch.profiler capture (Chrome trace + kernel table) of trace_steps steps after trace_skip (utils/trace.py)
+    trace_skip: int = 3
+    trace_steps: int = 5
     fault_inject: str = ""              # "rank:epoch:step" - raise there (failure-path tests: abort + --resume-latest)
 
     def replace(self, **kw: Any) -> "TrainConfig":
@@ -134,7 +138,7 @@ def build_parser(script: str) -> argparse.ArgumentParser:
             p.add_argument(flag, type=_str2bool, nargs="?", const=True, default=default)
         elif f.name in ("seed", "snapshot_epoch"):
             p.add_argument(flag, type=int, default=default)
-        elif f.name in ("snapshot_job_id", "pretrained"):
+        elif f.name in ("snapshot_job_id", "pretrained", "trace_dir"):
             p.add_argument(flag, type=str, default=default)
         else:
             p.add_argument(flag, type=type(default), default=default)

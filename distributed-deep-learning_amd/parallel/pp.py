@@ -36,6 +36,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from .. import comm
+from ..utils.trace import trace_range
 
 
 def split_sizes(batch: int, n: int) -> List[int]:
@@ -166,6 +167,15 @@ class PipelineStage:
 
     def forward(self, i: int, x: Optional[torch.Tensor], target: Optional[torch.Tensor],
                 loss_fn, train: bool) -> None:
+        with trace_range(f"Forward {i}"):          # the library's range names (schedules.py:757)
+            self._forward(i, x, target, loss_fn, train)
+
+    def backward(self, i: int, scale: float, last: bool) -> None:
+        with trace_range(f"Backward {i}"):         # schedules.py:785
+            self._backward(i, scale, last)
+
+    def _forward(self, i: int, x: Optional[torch.Tensor], target: Optional[torch.Tensor],
+                 loss_fn, train: bool) -> None:
         gs = self._gs
         if gs is None:
             return self._forward_eager(i, x, target, loss_fn, train)
@@ -193,7 +203,7 @@ class PipelineStage:
         if node.loss is not None:
             self.losses[i] = node.loss
 
-    def backward(self, i: int, scale: float, last: bool) -> None:
+    def _backward(self, i: int, scale: float, last: bool) -> None:
         gs = self._gs
         if gs is None:
             return self._backward_eager(i, scale, last)

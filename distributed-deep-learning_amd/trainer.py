@@ -38,6 +38,7 @@ from .parallel.pp import SCHEDULES, PipelineStage
 from .profiler import StepProfiler
 from .utils.arena import FlatArena, reverse_named_parameters
 from .utils.graph import GraphedTrainStep
+from .utils.trace import StepTrace, trace_range
 
 
 def set_seed(seed: int) -> None:
@@ -329,6 +330,7 @@ class Trainer:
         self.last_epoch_time = 0.0
         self.samples_per_sec = 0.0
         self._fault = tuple(int(v) for v in cfg.fault_inject.split(":")) if cfg.fault_inject else None
+        self._trace = StepTrace(cfg.trace_dir, strategy.global_rank, cfg.trace_skip, cfg.trace_steps)
 
         snap_job, snap_epoch = cfg.snapshot_job_id, cfg.snapshot_epoch
         if cfg.resume_latest and snap_job is None:
@@ -380,7 +382,9 @@ class Trainer:
                 break
             if self._fault == (s.global_rank, epoch, step):
                 raise RuntimeError(f"injected fault on rank {s.global_rank} at epoch {epoch} step {step} (--fault-inject)")
-            res = s.train_step(x, y, n)
+            self._trace.tick()
+            with trace_range(f"train step {step}"):
+                res = s.train_step(x, y, n)
             if res is not None:
                 loss, _out, preds = res
                 self._preds[seen:seen + n] = preds
@@ -389,6 +393,7 @@ class Trainer:
             seen += n
             if cfg.log_gradients and s.is_logger:
                 self._log_gradient(epoch * steps + step)
+        self._trace.close()                    # a window that runs past the epoch ends here
         self._print(f"Epoch {epoch} | Batchsize: {b_sz} | Steps: {steps}")
         return seen, steps
 

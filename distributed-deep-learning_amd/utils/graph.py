@@ -30,6 +30,7 @@ from typing import Callable, Dict, Optional, Tuple
 import torch
 
 from .. import ops
+from .trace import trace_range
 
 
 class _Captured:
@@ -133,19 +134,23 @@ class GraphedTrainStep:
             dp.pre_forward(training=True)
         if self.distributed:
             dp.arm(True)
-        c.graph.replay()
+        with trace_range("graph 0: forward + backward tail"):
+            c.graph.replay()
         if dp is not None:
             dp.after_forward()                 # graph 0 holds the whole forward: buffers are final behind it
         for i, g in enumerate(c.tail_graphs):
             for k in c.phase_segments[i]:      # buckets completed by the graph just enqueued
                 dp.segment_ready(k)
-            g.replay()
+            with trace_range(f"graph {i + 1}: backward phase"):
+                g.replay()
         if self.distributed:
             tok = self.profiler.begin("exposed_comm") if self.profiler else None
-            dp.finish_grad_sync()              # launches the remaining buckets, then fences
+            with trace_range("gradient sync fence"):
+                dp.finish_grad_sync()          # launches the remaining buckets, then fences
             if self.profiler:
                 self.profiler.end(tok)
-            self.optimizer.step()
+            with trace_range("adam"):
+                self.optimizer.step()
             dp.post_step()
         elif hasattr(self.optimizer, "_host_step"):
             self.optimizer._host_step += 1

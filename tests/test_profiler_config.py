@@ -59,3 +59,24 @@ def test_every_field_is_a_flag_and_new_switches_parse():
     assert TrainConfig().replace(batch_size=7).batch_size == 7
     with pytest.raises(SystemExit):
         parse_config("single", ["--no-such-flag"])
+
+
+def test_trace_ranges_and_profiler_capture(tmp_path):
+    """utils/trace.py: ranges are no-ops when off; StepTrace records a window of steps into a Chrome trace and a table."""
+    import json
+    import torch
+    from ddl.utils import trace
+    assert not trace.enabled()
+    with trace.trace_range("off"):
+        pass
+    st = trace.StepTrace(str(tmp_path / "tr"), rank=3, skip=1, steps=2)
+    for i in range(5):
+        st.tick()
+        with trace.trace_range(f"train step {i}"):
+            torch.ones(64, 64) @ torch.ones(64, 64)
+    assert st.done and not trace.enabled()
+    ev = json.load(open(tmp_path / "tr" / "trace_rank3.json"))["traceEvents"]
+    names = {e.get("name") for e in ev}
+    assert "train step 1" in names and "train step 2" in names and "train step 0" not in names and "train step 3" not in names
+    assert "aten::mm" in open(tmp_path / "tr" / "kernels_rank3.txt").read()
+    assert trace.StepTrace(None).done
