@@ -37,7 +37,7 @@ from .parallel.dp import DataParallelEngine
 from .parallel.pp import SCHEDULES, PipelineStage
 from .profiler import StepProfiler
 from .utils.arena import FlatArena, reverse_named_parameters
-from .utils.graph import GraphedTrainStep
+from .utils.graph import GraphedEvalStep, GraphedTrainStep
 from .utils.trace import StepTrace, trace_range
 
 
@@ -126,13 +126,14 @@ class SingleStrategy(Strategy):
         # replayed as one hipGraph launch after two eager warm-up steps
         self._step = GraphedTrainStep(self.model, self.optimizer, None, self.profiler,
                                       enabled=cfg.hip_graph and self.device.type == "cuda")
+        self._eval = GraphedEvalStep(self.model, enabled=cfg.hip_graph and cfg.impl != "torch")
 
     def train_step(self, x, y, batch_size):
         return self._step(x, y)
 
     @torch.no_grad()
     def eval_step(self, x, y, batch_size):
-        return self.model(x)
+        return self._eval(x)
 
 
 class DDPStrategy(Strategy):
@@ -153,6 +154,7 @@ class DDPStrategy(Strategy):
         self.is_logger = ctx.rank == 0
         self._step = GraphedTrainStep(self.model, self.optimizer, self.dp, self.profiler,
                                       enabled=cfg.hip_graph and self.device.type == "cuda")
+        self._eval = GraphedEvalStep(self.model, enabled=cfg.hip_graph and cfg.impl != "torch")
 
     @staticmethod
     def _native_kw(cfg, world):
@@ -170,7 +172,7 @@ class DDPStrategy(Strategy):
     @torch.no_grad()
     def eval_step(self, x, y, batch_size):
         self.dp.pre_forward()               # DDP broadcasts buffers in eval forwards too
-        return self.model(x)
+        return self._eval(x)
 
     def broadcast_flag(self, flag):
         return comm.broadcast_flag(flag, 0, self.device)            # ddp.py:223

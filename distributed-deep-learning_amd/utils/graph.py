@@ -181,3 +181,39 @@ class GraphedTrainStep:
             prof.end(tok)
             prof.step_done()
         return res
+
+
+class GraphedEvalStep:
+    """Inference forward of the native engine replayed as one hipGraph per input shape (the evaluation loop is
+    as launch-bound as training: ~250 kernels per batch).  The first batch of a shape runs eagerly, the second is
+    captured; the static output buffer is cloned on return (callers keep every batch's logits)."""
+
+    def __init__(self, model: torch.nn.Module, enabled: bool = True) -> None:
+        self.model, self.enabled = model, enabled
+        self._seen: Dict[Tuple, int] = {}
+        self._graphs: Dict[Tuple, Tuple] = {}
+        self._pool = None
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if not (self.enabled and x.is_cuda and not self.model.training):
+            return self.model(x)
+        key = (tuple(x.shape), x.dtype)
+        g = self._graphs.get(key)
+        if g is None:
+            n = self._seen.get(key, 0)
+            self._seen[key] = n + 1
+            if n < 1:
+                return self.model(x)
+            sx = x.clone()
+            torch.cuda.synchronize(x.device)
+            graph = torch.cuda.CUDAGraph()
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"):
+                out = self.model(sx)
+            g = self._graphs[key] = (graph, sx, out)
+        graph, sx, out = g
+        sx.copy_(x, non_blocking=True)
+        graph.replay()
+        return out.clone()

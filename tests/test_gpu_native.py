@@ -521,3 +521,23 @@ def test_bf16_mode_trains(dev):
     assert losses["bf16"][-1] < losses["bf16"][0]
     for a, b in zip(losses["fp32"], losses["bf16"]):
         assert abs(a - b) < 0.1 * max(1.0, abs(a)), (losses["fp32"], losses["bf16"])
+
+
+def test_graphed_eval_step_matches_eager(dev):
+    """GraphedEvalStep: eager first batch, captured second, replays after that - same logits as the eager model,
+    and every returned tensor keeps its own values (the evaluation loop concatenates them)."""
+    from ddl.models.densenet import UNIT_NAMES
+    from ddl.models.native_densenet import NativeDenseNetStage
+    from ddl.utils.graph import GraphedEvalStep
+    nat = NativeDenseNetStage(UNIT_NAMES, 5, dev).eval()
+    step = GraphedEvalStep(nat)
+    g = torch.Generator().manual_seed(0)
+    xs = [torch.randint(0, 256, (4, 3, 64, 64), dtype=torch.uint8, generator=g).to(dev) for _ in range(4)]
+    with torch.no_grad():
+        ref = [nat(x).clone() for x in xs]
+    got = [step(x) for x in xs]
+    assert len(step._graphs) == 1
+    for r, o in zip(ref, got):
+        torch.testing.assert_close(o, r, rtol=0, atol=0)
+    nat.train()
+    assert step(xs[0]).shape == (4, 5) and len(step._graphs) == 1      # training mode: never replayed
