@@ -541,3 +541,28 @@ def test_graphed_eval_step_matches_eager(dev):
         torch.testing.assert_close(o, r, rtol=0, atol=0)
     nat.train()
     assert step(xs[0]).shape == (4, 5) and len(step._graphs) == 1      # training mode: never replayed
+
+
+@pytest.mark.parametrize("B,S", [(1, 224), (5, 96), (33, 64), (7, 160), (2, 32)])
+def test_odd_batches_and_image_sizes_train(dev, B, S):
+    """Whole-model steps on shapes that leave every tile ragged (1 image, 33 images, 96/160/32-pixel inputs: 5x5, 3x3,
+    1x1 final maps): finite, decreasing loss on a fixed batch and the same first-step loss as the PyTorch model."""
+    from ddl import comm
+    from ddl.config import TrainConfig
+    from ddl.models.densenet import UNIT_NAMES
+    from ddl.trainer import SingleStrategy
+    cfg = TrainConfig(strategy="single", batch_size=B, impl="native")
+    strat = SingleStrategy(cfg, comm.CommContext(0, 1, 0, dev, "none"))
+    ref = _ref_stage(UNIT_NAMES, dev)
+    strat.model.import_state_dict(ref.state_dict())
+    g = torch.Generator().manual_seed(B * 1000 + S)
+    x = torch.randint(0, 256, (B, 3, S, S), dtype=torch.uint8, generator=g).to(dev)
+    y = torch.randint(0, 5, (B,), generator=g).to(dev)
+    ref.train()
+    if B > 1 or S > 32:            # PyTorch refuses batch statistics over a single value (B = 1 on a 1x1 map)
+        rl = float(F.cross_entropy(ref(x.float() / 255), y))
+    losses = [float(strat.train_step(x, y, B)[0]) for _ in range(5)]
+    assert all(l == l and abs(l) < 1e4 for l in losses), losses
+    assert losses[-1] < losses[0], losses
+    if B > 1 or S > 32:
+        assert abs(losses[0] - rl) < 2e-2 * max(1.0, abs(rl)), (losses[0], rl)
