@@ -168,13 +168,21 @@ __global__ void __launch_bounds__(1024) bn_bwd_prep_kernel(
   const int c0 = blockIdx.x * 32;
   const int ch = threadIdx.x & 31;
   const int c = c0 + ch;
+  // per-channel inputs are fetched ahead of the table reduction (a second dependent round trip otherwise)
+  const bool fin = threadIdx.x < 32 && c < C;
+  double mean = 0.0, rstd = 0.0, sc = 0.0;
+  float db_old = 0.f, dg_old = 0.f, k1_old = 0.f, k2_old = 0.f;
+  if (fin) {
+    mean = chan_mean[c]; rstd = chan_rstd[c]; sc = scale[c];
+    db_old = dbeta[c]; dg_old = dgamma[c];
+    if (mode != 0) { k1_old = k1[c]; k2_old = k2[c]; }
+  }
   reduce_partials32(partials, G, ldp, c0, s_a, s_b, red);
-  if (threadIdx.x < 32 && c < C) {
+  if (fin) {
     const double sg = s_a[ch], sgx = s_b[ch];
-    const double mean = chan_mean[c], rstd = chan_rstd[c], sc = scale[c];
     const double dgam = rstd * (sgx - mean * sg);
-    dbeta[c] += (float)sg;
-    dgamma[c] += (float)dgam;
+    dbeta[c] = db_old + (float)sg;
+    dgamma[c] = dg_old + (float)dgam;
     const double a = sg / count, b = dgam / count;
     const double kk1 = -sc * b * rstd;
     const double kk2 = -sc * a + sc * b * rstd * mean;
@@ -183,8 +191,8 @@ __global__ void __launch_bounds__(1024) bn_bwd_prep_kernel(
       k1[c] = (float)kk1;
       k2[c] = (float)kk2;
     } else {
-      k1[c] += (float)kk1;   // NQ
-      k2[c] += (float)kk2;   // NP
+      k1[c] = k1_old + (float)kk1;   // NQ
+      k2[c] = k2_old + (float)kk2;   // NP
     }
   }
 }
