@@ -179,6 +179,7 @@ def main() -> None:
             "launch": graph_mode,
             "grad_sync": "zero1 rs+ag(params)" if a.zero1 else "bucketed reduce-scatter + all-gather",
             "reducer": ("native" if getattr(getattr(strat, "dp", None), "_native", None) is not None else "python"),
+            "peak_mem_gib": (round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2) if dev.type == "cuda" else None),
         },
     }
     if a.profile:
