@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv3x3_halo_kernel(const ConvGe
   float* As = smem + soff;               // [R][LDA]
   float* Bs = As + R * LDA;              // [2][B_ELEMS]
 
-  const int tid = threadIdx.x, lane = tid & 63, wmn = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wmn = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wmn / WN, wn = wmn - wm * WN;
   const int li = lane & 31, lh = lane >> 5;
   int tile_x;
@@ -166,7 +166,6 @@ __global__ void __launch_bounds__(64 * WM * WN) conv3x3_halo_kernel(const ConvGe
       for (int j = 0; j < TN; ++j) bf[j] = ld4(Bb + j * 32 * LDA + 8 * s);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        if (n0 + (wn * TN + j) * 32 >= p.N) continue;      // wave-uniform: sub-tile beyond N
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -233,7 +232,7 @@ __global__ void __launch_bounds__(64 * (BM / 32) * KS) conv3x3_small_kernel(cons
   float* shs = smem + p.C;
   float* As = smem + (affine ? 2 * p.C : 0);           // [R][lda]
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-uniform guards branch on SCC
   const int ks = wid / WM, wm = wid - ks * WM;
   const int li = lane & 31, lh = lane >> 5;
   int tile_x;

@@ -87,7 +87,9 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
   __bf16* Ah = reinterpret_cast<__bf16*>(smem + soff);   // BF: [NBUF][BM][LDH]
   __bf16* Bh = Ah + NBUF * BM * LDH;                     //     [NBUF][BN][LDH]
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // wave index as a scalar: the wave-uniform sub-tile guards then branch on SCC instead of masking EXEC
+  // (the BN = 32 forms have no live guard; scalarising them only moves an index table to scratch)
+  const int tid = threadIdx.x, lane = tid & 63, wid = BN == 32 ? tid >> 6 : __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ks = wid / (WM * WN);
   const int wmn = wid - ks * (WM * WN);
   const int wm = wmn / WN, wn = wmn - wm * WN;

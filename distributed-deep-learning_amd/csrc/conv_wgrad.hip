@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256) wgrad1x1_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ds = smem;                     // [2][RK][128]
   float* As = smem + 2 * RK * 128;      // [2][RK][128]
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar wave index
   const int wm = wid >> 1, wn = wid & 1;
   const int li = lane & 31, lh = lane >> 5;
   const int ctiles = (p.C + 127) / 128, ntiles = (p.N + 127) / 128;
@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(256) wgrad3x3_kernel(const WgradParams p) {
   float* Ds = smem;                                // [2][RK][32]
   float* As = smem + 2 * RK * 32;                  // [2][AR][128]
   int* Fl = reinterpret_cast<int*>(smem + 2 * RK * 32 + 2 * AR * 128);   // [2][RK]
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar wave index
   const int li = lane & 31, lh = lane >> 5;
   const int ctiles = (p.C + 127) / 128;
   int t_idx, chunk;
