@@ -143,12 +143,15 @@ class _BlockFn(torch.autograd.Function):
         # Weight gradients feed nothing downstream, so they run on a side stream beside the
         # data-gradient chain (parallel branches once the step is captured into a hipGraph).
         # g2 / k are double-buffered by layer parity so a layer's 1x1 wgrad may still be reading
-        # them while the next layer's 3x3 dgrad runs.
+        # them while the next layer's 3x3 dgrad runs.  (Measured at batch 30: 1 buffer 11.65 ms/step,
+        # 2: 9.31, 3: 9.53, 4: 9.68, 6: 10.03 - a weight-gradient stream that lags further reads
+        # operands that have left the L2.)
         side = unit.stage.side_stream if unit.stage.overlap_wgrad else None
         main = torch.cuda.current_stream(buf.device)
-        k = torch.empty(2, 3, MID, **f32)
-        g2 = torch.empty(2, M, MID, **f32)
-        done = [None, None]
+        NB = unit.stage.g2_bufs
+        k = torch.empty(NB, 3, MID, **f32)
+        g2 = torch.empty(NB, M, MID, **f32)
+        done = [None] * NB
         min_rows = unit.stage.wgrad_min_rows
         bf = unit.stage.bf16
         fused = unit.stage.fused_bwd
@@ -157,7 +160,7 @@ class _BlockFn(torch.autograd.Function):
         for l in range(L - 1, -1, -1):
             lay = unit.layers[l]
             C = C0 + GROWTH * l
-            par = l & 1
+            par = l % NB
             sl = slice(C, C + GROWTH)
             dy, xs = d2d[:, sl], buf2d[:, sl]
             sc2, sh2 = bn2[l, 3], bn2[l, 4]
@@ -464,6 +467,8 @@ class NativeDenseNetStage(nn.Module):
         # (10.23 ms), so it is opt-in: DDL_FUSED_BWD=1 (it does win with eager launches).
         self.fused_stats = os.environ.get("DDL_FUSED_STATS", "1") == "1"
         self.fused_bwd = os.environ.get("DDL_FUSED_BWD", "0") == "1"
+        # g2 / k buffers of the dense-block backward: how many layers the weight-gradient stream may lag
+        self.g2_bufs = max(1, int(os.environ.get("DDL_G2_BUFS", "2")))
         ops.require_ext()
         device = torch.device(device)
         if device.type != "cuda":
