@@ -5,7 +5,7 @@ Metric / config = BASELINE.json: the reference's workload (DenseNet-121, 3x224x2
 defaults, fp32 like the reference, per-GPU batch 30 = single.py's batch) under data parallelism on
 N MI355X of one node (N=1 is the single-device baseline).  Synthetic uint8 images generated in
 HBM, random-init weights.  A timed step is the full training step: input normalisation, forward,
-fused softmax-CE, backward, bucketed RCCL gradient reduce-scatter/all-gather, fused Adam.
+fused softmax-CE, backward, bucketed RCCL gradient all-reduce (or reduce-scatter + all-gather), fused Adam.
 
     python bench.py                       # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -41,6 +41,8 @@ def main() -> None:
     ap.add_argument("--microbatches", type=int, default=5)
     ap.add_argument("--pp-size", type=int, default=2)
     ap.add_argument("--bucket-mb", type=float, default=8.0)
+    ap.add_argument("--grad-sync", choices=["rs_ag", "allreduce"], default=None,
+                    help="per-bucket collective (default: TrainConfig.grad_sync)")
     ap.add_argument("--zero1", action="store_true")
     ap.add_argument("--sync-buffers", default="forward", choices=["forward", "epoch", "off"],
                     help="BN buffer broadcast policy (forward = DDP parity, the default)")
@@ -74,7 +76,8 @@ def main() -> None:
                           num_microbatches=a.microbatches, schedule=a.schedule, pp_size=pp_size,
                           split_points=default_split_points(max(pp_size, 1)), profile=a.profile,
                           sync_buffers=a.sync_buffers, num_workers=0,
-                          **({} if a.grad_phases is None else {"grad_phases": a.grad_phases}))
+                          **({} if a.grad_phases is None else {"grad_phases": a.grad_phases}),
+                          **({} if a.grad_sync is None else {"grad_sync": a.grad_sync}))
         return build_strategy(cfg, ctx)
 
     strat = make_strategy(not a.no_graph)
@@ -177,7 +180,9 @@ def main() -> None:
             "baseline": f"{base_key} {BASELINE[base_key]} samples/s (BASELINE.md sec. 2)",
             "impl": impl,
             "launch": graph_mode,
-            "grad_sync": "zero1 rs+ag(params)" if a.zero1 else "bucketed reduce-scatter + all-gather",
+            "grad_sync": ("zero1 rs+ag(params)" if a.zero1 else
+                          "bucketed all-reduce" if getattr(getattr(strat, "dp", None), "grad_sync", "") == "allreduce"
+                          else "bucketed reduce-scatter + all-gather"),
             "reducer": ("native" if getattr(getattr(strat, "dp", None), "_native", None) is not None else "python"),
             "peak_mem_gib": (round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2) if dev.type == "cuda" else None),
         },

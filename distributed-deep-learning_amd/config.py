@@ -58,7 +58,7 @@ class TrainConfig:
     #   ^ torchvision densenet121 state-dict file (reference: weights=IMAGENET1K_V1, single.py:297)
     # ---- data parallel -------------------------------------------------------
     bucket_mb: float = 8.0              # gradient bucket size (MiB); sized for xGMI, not NVSwitch
-    grad_sync: str = "rs_ag"            # rs_ag (reduce-scatter + all-gather) | allreduce
+    grad_sync: str = "allreduce"        # allreduce (one RCCL kernel per bucket) | rs_ag (reduce-scatter + all-gather; forced by --zero1)
     zero1: bool = False                 # shard the Adam step over the dp group (RS grads, AG params)
     sync_buffers: str = "forward"       # forward (DDP parity) | epoch | off
     grad_phases: str = "denseblock3,denseblock2"   # units that open a new backward graph phase (DP overlap)

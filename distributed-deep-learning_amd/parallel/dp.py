@@ -55,7 +55,8 @@ class DataParallelEngine:
         # the real RCCL path - comm stream, fences, phased graphs - end to end; tests/test_gpu_dist.py)
         self.single = self.world == 1 and not (comm.is_dist() and comm.force_collectives())
         self.device = torch.device(device) if device is not None else next(module.parameters()).device
-        self.grad_sync = grad_sync
+        # ZeRO-1 needs the scattered form (each rank keeps only its shard of the reduced gradient)
+        self.grad_sync = "rs_ag" if zero1 else grad_sync
         self.sync_buffers_policy = sync_buffers
         self.zero1 = zero1
         self.profiler = profiler
@@ -97,7 +98,7 @@ class DataParallelEngine:
             self._native = ops.require_ext().BucketReducer(
                 self.arena.flat_grad, [s.start for s in segs], [s.end for s in segs], list(self._slot_segment),
                 pending, group if group is not None else dist.group.WORLD, self.rank, self.world, bool(zero1),
-                grad_sync == "allreduce", bool(debug_sync), bool(profiler is not None and profiler.enabled),
+                self.grad_sync == "allreduce", bool(debug_sync), bool(profiler is not None and profiler.enabled),
                 cs.stream_id, cs.device_index, cs.device_type)
             if profiler is not None:
                 profiler.add_source("rccl", self._native.drain_ms, self._native.set_timing)
