@@ -8,3 +8,10 @@ Layers:
   optim / trainer / profiler                fused flat Adam, the one Trainer, compute/comm profiler
 """
 __version__ = "0.1.0"
+
+import os as _os
+
+# Multi-process GPU work (RCCL, tensors shared across processes) needs dmabuf IPC handles on hosts whose
+# driver has no legacy IPC; must be in the environment before the HIP runtime starts.  An explicit
+# setting wins.
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
