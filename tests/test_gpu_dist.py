@@ -251,3 +251,33 @@ def test_debug_sync_matches_overlapped_run(tmp_path):
         assert m, out[-2000:]
         losses.append(float(m.group(1)))
     assert losses[0] == losses[1], losses
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_arena_layout_for_the_drivers_world_sizes(world):
+    """The 2/4/8-GPU runs are the driver's; what can be checked on one GPU is that the full model's
+    arena, cut for that world size with the default bucket size and backward phases, satisfies what
+    the native reducer's constructor and the shard arithmetic demand."""
+    from ddl.config import TrainConfig
+    from ddl.models import create_stage
+    from ddl.models.densenet import UNIT_NAMES
+    cfg = TrainConfig()
+    phases = tuple(u for u in cfg.grad_phases.split(",") if u)
+    model = create_stage(UNIT_NAMES, torch.device("cuda", 0), "native", 5, bucket_mb=cfg.bucket_mb,
+                         dp_world=world, grad_phases=phases)
+    arena = model.arena
+    assert len(arena.segments) >= len(phases) + 1
+    covered = 0
+    for k, seg in enumerate(arena.segments):
+        assert (seg.end - seg.start) % world == 0 and (seg.end - seg.start) % 64 == 0
+        assert seg.start == covered                      # contiguous, no gaps between segments
+        covered = seg.end
+    assert covered == arena.flat_grad.numel() and arena.flat_param.numel() == covered
+    n_params = sum(p.numel() for p in model.parameters())
+    assert n_params == 6_958_981 and covered >= n_params
+    # every parameter lies inside exactly one segment (a bucket never splits a tensor)
+    starts = [s.start for s in arena.segments] + [covered]
+    for name, p in model.named_parameters():
+        off = (p.data_ptr() - arena.flat_param.data_ptr()) // 4
+        k = max(i for i, s in enumerate(starts[:-1]) if s <= off)
+        assert off + p.numel() <= starts[k + 1], name
