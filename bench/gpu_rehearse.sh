@@ -11,6 +11,9 @@ run() {  # name nproc args...
   if [ $rc -ne 0 ]; then tail -30 gpurun_out/rehearse/$name.err; exit $rc; fi
 }
 run ddp2 2 --mode ddp &&
+run ddp4 4 --mode ddp &&
+run ddp2_rsag 2 --mode ddp --grad-sync rs_ag &&
+run ddp2_zero1 2 --mode ddp --zero1 &&
 run ddp2_nograph 2 --mode ddp --no-graph &&
 run pp2_1f1b 2 --mode pp &&
 run pp2_1f1b_nograph 2 --mode pp --no-graph &&
