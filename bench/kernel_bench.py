@@ -9,7 +9,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from ddl import ops
-from ddl.models.native_densenet import NativeDenseNetStage
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=30)

@@ -12,7 +12,7 @@ from typing import List, Optional
 import torch
 
 from . import comm
-from .config import TrainConfig, parse_config
+from .config import parse_config
 from .data import build_loaders
 from .trainer import Trainer, build_strategy, job_id_from_env, set_seed
 

@@ -24,7 +24,7 @@ import datetime
 import hashlib
 import os
 from dataclasses import dataclass
-from typing import List, Optional, Sequence
+from typing import List, Optional
 
 import torch
 import torch.distributed as dist

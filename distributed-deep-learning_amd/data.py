@@ -27,7 +27,7 @@ import csv
 import math
 import os
 from pathlib import Path
-from typing import Iterator, List, Optional, Tuple
+from typing import Iterator, List, Tuple
 
 import numpy as np
 import torch

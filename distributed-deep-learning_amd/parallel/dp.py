@@ -34,7 +34,7 @@ from __future__ import annotations
 import os
 import time
 from contextlib import contextmanager
-from typing import Callable, List, Optional
+from typing import Callable, List
 
 import torch
 import torch.distributed as dist

@@ -33,7 +33,6 @@ from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
-import torch.nn.functional as F
 
 from .. import comm
 from ..utils.trace import trace_range

@@ -23,7 +23,7 @@ its phased backward graphs, so a phase's buckets are complete when its graph has
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, Iterable, List, Sequence, Tuple
+from typing import Iterable, List, Sequence, Tuple
 
 import torch
 

@@ -25,7 +25,7 @@ Protocol
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, Optional, Tuple
+from typing import Dict, Tuple
 
 import torch
 
