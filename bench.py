@@ -138,6 +138,7 @@ def main() -> None:
     for i in range(a.steps):
         x, y = pool[i % len(pool)]
         strat.train_step(x, y, B)
+    host_dt = time.perf_counter() - t0          # host time to ISSUE the steps (no device wait in the loop)
     sync()
     dt = time.perf_counter() - t0
     if a.profile:
@@ -184,6 +185,7 @@ def main() -> None:
                           "bucketed all-reduce" if getattr(getattr(strat, "dp", None), "grad_sync", "") == "allreduce"
                           else "bucketed reduce-scatter + all-gather"),
             "reducer": ("native" if getattr(getattr(strat, "dp", None), "_native", None) is not None else "python"),
+            "host_issue_ms_per_step": round(host_dt / a.steps * 1e3, 3),
             "peak_mem_gib": (round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2) if dev.type == "cuda" else None),
         },
     }
