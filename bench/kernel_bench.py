@@ -98,6 +98,11 @@ for (blk, H, Cl, Cf) in [("b1", 56, 160, 256), ("b2", 28, 320, 512), ("b3", 14, 
                            a.bm, a.bf16)
     cases.append((f"{blk}_fwd3x3_fused", 2.0 * M * 1152 * 32, f2f))
 
+    def f2a(M=M, h=h, sc=sc, sh=sh, w2=w2, buf=buf, Cl=Cl, H=H, acc_out=acc_out):      # tables in, accumulators out
+        ext.conv_gemm(h, None, sc, None, sh, True, M, H, H, 9, False, w2, False, buf[:, Cl:Cl + 32], False, False,
+                      None, None, None, 1, a.bm, a.bf16, acc_out=acc_out[:, :, :32])
+    cases.append((f"{blk}_fwd3x3_accout", 2.0 * M * 1152 * 32, f2a))
+
     def f3(M=M, dbuf=dbuf, buf=buf, Cl=Cl, ones=ones, sc=sc, sh=sh, w2=w2, g2=g2, h=h, H=H):
         ext.conv_gemm(dbuf[:, Cl:Cl + 32], buf[:, Cl:Cl + 32], ones[:32], sc[:32], sh[:32], False, M, H, H, 9, True,
                       w2, True, g2, True, False, h, sc, sh, 2, a.bm, a.bf16)
