@@ -40,17 +40,22 @@ void launch_normalize_u8(const uint8_t* in, float* out, int B, int C, int H, int
 // ---------------------------------------------------------------------------------------
 // K10/K11: one thread per row (C is tiny: 5 classes).  loss = mean_i (lse_i - z_i[t_i]);
 // dlogits = (softmax - onehot) / B; preds = argmax (first max, like torch.argmax).
-// Block partial sums go through a wave shuffle + LDS reduction, one atomic per block.
+// ONE workgroup of 1024 threads walks the rows (a per-GPU batch is at most a few thousand rows of 5
+// floats - the kernel is pure launch latency) and the loss is combined in a FIXED order: per-thread
+// running sum in row order, wave shuffle tree, the 16 wave sums added left to right.  No float atomics,
+// no memset node: the result is bit-identical from run to run at any batch size.
+// A target outside [0, C) (torch raises a device assert there) poisons the loss with NaN and gets a
+// zero gradient row instead of reading out of bounds.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) ce_fwd_bwd_kernel(const float* __restrict__ logits,
-                                                         const int64_t* __restrict__ targets,
-                                                         float* __restrict__ loss,
-                                                         float* __restrict__ dlogits,
-                                                         int64_t* __restrict__ preds, int B, int C) {
-  __shared__ float wave_sums[4];
+__global__ void __launch_bounds__(1024) ce_fwd_bwd_kernel(const float* __restrict__ logits,
+                                                          const int64_t* __restrict__ targets,
+                                                          float* __restrict__ loss,
+                                                          float* __restrict__ dlogits,
+                                                          int64_t* __restrict__ preds, int B, int C) {
+  __shared__ float wave_sums[16];
   float local = 0.f;
   const float invB = 1.0f / (float)B;
-  for (int r = blockIdx.x * 256 + threadIdx.x; r < B; r += gridDim.x * 256) {
+  for (int r = threadIdx.x; r < B; r += 1024) {
     const float* z = logits + (long)r * C;
     float mx = z[0];
     int arg = 0;
@@ -61,13 +66,15 @@ __global__ void __launch_bounds__(256) ce_fwd_bwd_kernel(const float* __restrict
     float sum = 0.f;
     for (int c = 0; c < C; ++c) sum += __expf(z[c] - mx);
     float lse = mx + __logf(sum);
-    int t = (int)targets[r];
-    local += lse - z[t];
+    const int64_t t64 = targets[r];
+    const bool ok = t64 >= 0 && t64 < C;
+    const int t = ok ? (int)t64 : 0;
+    local += ok ? lse - z[t] : __builtin_nanf("");
     float inv = 1.0f / sum;
     float* dz = dlogits + (long)r * C;
     for (int c = 0; c < C; ++c) {
       float p = __expf(z[c] - mx) * inv;
-      dz[c] = (p - (c == t ? 1.f : 0.f)) * invB;
+      dz[c] = ok ? (p - (c == t ? 1.f : 0.f)) * invB : 0.f;
     }
     preds[r] = arg;
   }
@@ -76,17 +83,15 @@ __global__ void __launch_bounds__(256) ce_fwd_bwd_kernel(const float* __restrict
   if (lane == 0) wave_sums[wid] = local;
   __syncthreads();
   if (threadIdx.x == 0) {
-    float tot = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
-    atomicAdd(loss, tot * invB);
+    float tot = 0.f;
+    for (int w = 0; w < 16; ++w) tot += wave_sums[w];
+    loss[0] = tot * invB;
   }
 }
 
 void launch_ce_fwd_bwd(const float* logits, const int64_t* targets, float* loss, float* dlogits,
                        int64_t* preds, int B, int C, hipStream_t s) {
-  hipMemsetAsync(loss, 0, sizeof(float), s);
-  int grid = (B + 255) / 256;
-  if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(grid), dim3(256), 0, s, logits, targets, loss, dlogits,
+  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, logits, targets, loss, dlogits,
                      preds, B, C);
 }
 

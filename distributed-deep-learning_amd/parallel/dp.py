@@ -293,6 +293,19 @@ class DataParallelEngine:
                 comm.all_gather_into(full, full[self.rank * n:(self.rank + 1) * n], self.group)
         self._timed(run)
 
+    def gather_sharded(self, *flats: torch.Tensor) -> None:
+        """ZeRO-1: every rank owns only its 1/W slice of each arena segment of a sharded buffer (Adam's
+        ``exp_avg`` / ``exp_avg_sq``); all-gather the slices in place so that every rank holds the full buffer.
+        Called before a snapshot (DCP de-duplicates replicated keys across DP ranks and would otherwise write
+        one rank's mostly-zero copy) - the same pattern as ``post_step`` for the parameters."""
+        if not self.zero1 or self.single:
+            return
+        for flat in flats:
+            for seg in self.arena.segments:
+                full = flat[seg.start:seg.end]
+                n = (seg.end - seg.start) // self.world
+                comm.all_gather_into(full, full[self.rank * n:(self.rank + 1) * n], self.group)
+
     # ------------------------------------------------------------------ metric helpers
     def gather(self, t: torch.Tensor) -> torch.Tensor:
         return comm.all_gather_flat(t, self.group) if self.world > 1 else t

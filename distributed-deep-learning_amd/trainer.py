@@ -360,6 +360,11 @@ class Trainer:
 
     def _save_snapshot(self, epoch: int) -> None:
         path = ckpt.snapshot_path(self.cfg.ckpt_subdir, self.job_id, epoch)
+        dp, opt = self.s.dp, self.s.optimizer
+        if dp is not None and dp.zero1 and hasattr(opt, "exp_avg"):
+            # ZeRO-1: each rank's Adam moments are valid on its 1/W shard only - make them whole before DCP
+            # de-duplicates the (identically keyed) optimizer state across the DP replicas
+            dp.gather_sharded(opt.exp_avg, opt.exp_avg_sq)
         ckpt.save_snapshot(path, epoch, self.s.model, self.s.optimizer, self.s.ckpt_suffix)
         self._print(f"Epoch {epoch} | Saved snapshot to {path}")
 

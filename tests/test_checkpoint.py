@@ -83,3 +83,101 @@ def test_stage_checkpoints_partition_the_single_key_space(tmp_path):
     for i, units in enumerate(dn.stage_units(["features.denseblock3.denselayer1"])):
         got |= set(dn.DenseNetStage(units).state_dict())
     assert got == full
+
+
+# ---------------------------------------------------------------------------------------------------
+# Interop with the reference's own AppState (single.py:68-89, pp.py:77-99): get_state_dict / set_state_dict +
+# dcp.save / dcp.load.  "Same checkpoint format" means a snapshot written by either side loads on the other.
+# ---------------------------------------------------------------------------------------------------
+class _RefAppState(torch.distributed.checkpoint.stateful.Stateful):
+    """The reference's Stateful wrapper, re-stated from its description: model/optim state through
+    ``get_state_dict`` / ``set_state_dict``, keys ``model{S}`` / ``optim{S}`` / ``epoch``."""
+
+    def __init__(self, epoch, model, optimizer, suffix=""):
+        self.epoch, self.model, self.optimizer, self.suffix = epoch, model, optimizer, suffix
+
+    def state_dict(self):
+        from torch.distributed.checkpoint.state_dict import get_state_dict
+        m, o = get_state_dict(self.model, self.optimizer)
+        return {f"model{self.suffix}": m, f"optim{self.suffix}": o, "epoch": torch.tensor(self.epoch)}
+
+    def load_state_dict(self, sd):
+        from torch.distributed.checkpoint.state_dict import set_state_dict
+        set_state_dict(self.model, self.optimizer, model_state_dict=sd[f"model{self.suffix}"],
+                       optim_state_dict=sd[f"optim{self.suffix}"])
+        self.epoch = int(sd["epoch"])
+
+
+def _train_two_steps(model, opt, shape, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    for _ in range(2):
+        opt.zero_grad()
+        (model(torch.randn(*shape, generator=g)).square().mean() * 1e4).backward()   # keep gradients far above Adam's eps
+        opt.step()
+
+
+def _assert_same_state(m_a, o_a, m_b, o_b):
+    sa, sb = m_a.state_dict(), m_b.state_dict()
+    assert set(sa) == set(sb)
+    for k in sa:
+        torch.testing.assert_close(sa[k], sb[k], rtol=0, atol=0)
+    pa, pb = dict(m_a.named_parameters()), dict(m_b.named_parameters())
+    for n in pa:
+        for key in ("exp_avg", "exp_avg_sq"):
+            torch.testing.assert_close(o_a.state[pa[n]][key], o_b.state[pb[n]][key], rtol=0, atol=0)
+        assert float(o_a.state[pa[n]]["step"]) == float(o_b.state[pb[n]]["step"])
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("units,suffix,shape", [
+    (dn.UNIT_NAMES, "", (2, 3, 64, 64)),                                      # single.py / ddp.py layout
+    (dn.stage_units(["features.denseblock3.denselayer1"])[1], "1", (2, 256, 4, 4)),   # pp.py stage 1: model1 / optim1
+])
+def test_snapshot_written_here_loads_through_the_reference_appstate(tmp_path, units, suffix, shape):
+    torch.manual_seed(0)
+    m = dn.DenseNetStage(units, 5)
+    opt = FusedAdam(FlatArena(reverse_named_parameters(m)))
+    _train_two_steps(m, opt, shape)
+    path = str(tmp_path / "mine")
+    ck.save_snapshot(path, 7, m, opt, suffix=suffix)
+
+    torch.manual_seed(1)
+    m2 = dn.DenseNetStage(units, 5)
+    opt2 = torch.optim.Adam(m2.parameters())
+    app = _RefAppState(0, m2, opt2, suffix)
+    dcp.load({"app": app}, checkpoint_id=path)                                # the reference's _load_snapshot
+    assert app.epoch == 7
+    _assert_same_state(m, opt, m2, opt2)
+    # and training continues identically from the restored state on both sides
+    _train_two_steps(m, opt, shape, seed=9)
+    _train_two_steps(m2, opt2, shape, seed=9)
+    for (n, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
+        torch.testing.assert_close(p, q, rtol=1e-4, atol=3e-4, msg=lambda s, n=n: f"{n}: {s}")   # two Adam implementations; lr = 1e-3 per step
+
+
+@pytest.mark.parametrize("units,suffix,shape", [
+    (dn.UNIT_NAMES, "", (2, 3, 64, 64)),
+    (dn.stage_units(["features.denseblock3.denselayer1"])[0], "0", (2, 3, 64, 64)),   # pp.py stage 0
+])
+def test_snapshot_written_by_the_reference_appstate_loads_here(tmp_path, units, suffix, shape):
+    torch.manual_seed(0)
+    m = dn.DenseNetStage(units, 5)
+    opt = torch.optim.Adam(m.parameters())
+    _train_two_steps(m, opt, shape)
+    path = str(tmp_path / "ref")
+    dcp.save({"app": _RefAppState(3, m, opt, suffix)}, checkpoint_id=path)    # the reference's _save_snapshot
+
+    torch.manual_seed(1)
+    m2 = dn.DenseNetStage(units, 5)
+    opt2 = FusedAdam(FlatArena(reverse_named_parameters(m2)))
+    ptr = opt2.arena.flat_param.data_ptr()
+    assert ck.load_snapshot(path, m2, opt2, suffix=suffix) == 3
+    assert opt2.arena.flat_param.data_ptr() == ptr                            # loaded into the arena views
+    _assert_same_state(m, opt, m2, opt2)
+    assert opt2._host_step == 2
+    _train_two_steps(m, opt, shape, seed=9)
+    _train_two_steps(m2, opt2, shape, seed=9)
+    for (n, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
+        torch.testing.assert_close(p, q, rtol=1e-4, atol=3e-4, msg=lambda s, n=n: f"{n}: {s}")   # two Adam implementations; lr = 1e-3 per step

@@ -110,6 +110,62 @@ def test_dp_gradients_equal_single_process(grad_sync, zero1):
     run_distributed(_dp_worker, 2, grad_sync, zero1)
 
 
+def _zero1_snapshot_worker(rank, world, path):
+    """ZeRO-1 + snapshot: each rank's Adam moments are valid on its 1/W shard only; the snapshot must hold
+    the whole state (DCP de-duplicates replicated keys -> (W-1)/W of the moments saved as zeros)."""
+    from ddl import checkpoint as ck
+    from ddl.optim import FusedAdam
+    from ddl.parallel.dp import DataParallelEngine
+
+    def make():
+        model = _bn_free_net()
+        dp = DataParallelEngine(model, device="cpu", bucket_mb=0.0005, zero1=True)
+        return model, dp, FusedAdam(dp.arena, shard=(rank, world))
+
+    def step(model, dp, opt, X, Y):
+        opt.zero_grad()
+        dp.arm(True)
+        F.cross_entropy(model(X[rank * 4:(rank + 1) * 4]), Y[rank * 4:(rank + 1) * 4]).backward()
+        dp.finish_grad_sync()
+        opt.step()
+        dp.post_step()
+
+    g = torch.Generator().manual_seed(11)
+    batches = [(torch.randn(4 * world, 3, 8, 8, generator=g), torch.randint(0, 5, (4 * world,), generator=g))
+               for _ in range(4)]
+    model, dp, opt = make()
+    ref = _bn_free_net()                                   # unsharded single-process oracle
+    ref_opt = torch.optim.Adam(ref.parameters())
+    for X, Y in batches[:2]:
+        step(model, dp, opt, X, Y)
+        ref_opt.zero_grad()
+        F.cross_entropy(ref(X), Y).backward()
+        ref_opt.step()
+    dp.gather_sharded(opt.exp_avg, opt.exp_avg_sq)         # what Trainer._save_snapshot does under --zero1
+    for p, q in zip(model.parameters(), ref.parameters()):
+        torch.testing.assert_close(opt.state[p]["exp_avg"], ref_opt.state[q]["exp_avg"], rtol=1e-4, atol=1e-7)
+        torch.testing.assert_close(opt.state[p]["exp_avg_sq"], ref_opt.state[q]["exp_avg_sq"], rtol=1e-4, atol=1e-9)
+    ck.save_snapshot(path, 0, model, opt)
+    for X, Y in batches[2:]:
+        step(model, dp, opt, X, Y)                         # the uninterrupted run
+    # resume into a fresh, differently initialised replica set
+    torch.manual_seed(999 + rank)
+    model2, dp2, opt2 = make()
+    for p in model2.parameters():
+        p.data.add_(0.5)
+    assert ck.load_snapshot(path, model2, opt2) == 0
+    n_nonzero = int((opt2.exp_avg != 0).sum())
+    assert n_nonzero > 0.9 * dp2.arena.total_param_numel()          # not the mostly-zero state of one rank
+    for X, Y in batches[2:]:
+        step(model2, dp2, opt2, X, Y)
+    for p, q in zip(model.parameters(), model2.parameters()):
+        torch.testing.assert_close(p, q, rtol=0, atol=0)           # resumed == uninterrupted, bit for bit
+
+
+def test_zero1_snapshot_resume_equals_uninterrupted_run(tmp_path):
+    run_distributed(_zero1_snapshot_worker, 2, str(tmp_path / "snap"))
+
+
 def _dp_buffers_worker(rank, world):
     from ddl.parallel.dp import DataParallelEngine
     torch.manual_seed(rank)
