@@ -5,20 +5,33 @@ Metric / config = BASELINE.json: the reference's workload (DenseNet-121, 3x224x2
 defaults, fp32 like the reference, per-GPU batch 30 = single.py's batch) under data parallelism on
 N MI355X of one node (N=1 is the single-device baseline).  Synthetic uint8 images generated in
 HBM, random-init weights.  A timed step is the full training step: input normalisation, forward,
-fused softmax-CE, backward, bucketed RCCL gradient all-reduce (or reduce-scatter + all-gather), fused Adam.
+fused softmax-CE, backward, bucketed RCCL reduce-scatter + all-gather (or all-reduce), fused Adam.
 
     python bench.py                       # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0.  Scaling is weak (per-GPU batch fixed).  ``--mode pp|ddpnpp``
-benchmarks the pipeline / hybrid strategies instead of DDP.
+benchmarks the pipeline / hybrid strategies instead of DDP; ``--preset mi355x`` sizes them for the
+hardware (per-replica batch 240 = 8 micro-batches of 30, stages balanced on measured unit times)
+where the default ``--preset parity`` keeps the reference's sizes (30 = 5 micro-batches of 6, split at
+denseblock3).
+
+Failure policy: a step that cannot be captured / run is a FAILED benchmark - the error is printed and the
+process exits non-zero (no silent re-measurement on another path).  ``host_bound`` in the JSON (and a
+warning on stderr) flags a run whose host needed more than 80 % of the step time just to issue it.
+
+With more than one rank (or ``--ab``) extra steps BEHIND the timed region measure both per-bucket
+collective forms on the same captured step (``grad_sync_ab``) and two more bucket sizes
+(``bucket_mb_sweep``), and the compute / RCCL / exposed-communication split is reported as the maximum
+over ranks (``profile``) - one multi-GPU run returns the tuning data.
 """
 import argparse
 import json
 import os
 import sys
 import time
+import traceback
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
@@ -27,19 +40,27 @@ import torch  # noqa: E402
 # reference numbers, BASELINE.md section 2 (samples/s, derived from the published epoch times)
 BASELINE = {"single": 26.4, "ddp": 39.3, "pp": 21.6, "ddpnpp": 17.7}
 
+# per-replica batch / micro-batches / split policy of the pipeline modes
+PRESETS = {
+    "parity": dict(batch=30, microbatches=5, split="reference"),     # pp.py:365,378-386
+    "mi355x": dict(batch=240, microbatches=8, split="auto"),         # 8 micro-batches of 30: the single-GPU kernel regime
+}
+
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--batch-per-gpu", type=int, default=30)
+    ap.add_argument("--batch-per-gpu", type=int, default=None, help="per-replica batch (default: 30, or the preset's)")
     ap.add_argument("--mode", default="ddp", choices=["ddp", "pp", "ddpnpp"])
-    ap.add_argument("--impl", default="auto", choices=["auto", "native", "torch"])
+    ap.add_argument("--preset", default="parity", choices=sorted(PRESETS))
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--schedule", default="1f1b")
-    ap.add_argument("--microbatches", type=int, default=5)
+    ap.add_argument("--microbatches", type=int, default=None)
     ap.add_argument("--pp-size", type=int, default=2)
+    ap.add_argument("--split-points", nargs="+", default=None,
+                    help="stage starts (reference module names) or 'auto' (balance on measured unit times)")
     ap.add_argument("--bucket-mb", type=float, default=8.0)
     ap.add_argument("--grad-sync", choices=["rs_ag", "allreduce"], default=None,
                     help="per-bucket collective (default: TrainConfig.grad_sync)")
@@ -51,6 +72,9 @@ def main() -> None:
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--backend", default="auto", help="auto = RCCL; gloo lets several ranks share one GPU (rehearsal only)")
     ap.add_argument("--profile", action="store_true", help="add the compute/RCCL breakdown to the JSON")
+    ap.add_argument("--ab", default="auto", choices=["auto", "on", "off"],
+                    help="grad_sync A/B + bucket-size sweep on extra steps behind the timed region (auto: when W>1)")
+    ap.add_argument("--ab-steps", type=int, default=12)
     a = ap.parse_args()
 
     from ddl import comm
@@ -65,22 +89,43 @@ def main() -> None:
         a.profile = True      # event-based compute / RCCL / exposed-communication split (no host sync in the loop)
     ctx = comm.init(a.backend, "auto", force=True)
     dev = ctx.device
-    B = a.batch_per_gpu
+    preset = PRESETS[a.preset]
+    pipeline = a.mode != "ddp"
+    B = a.batch_per_gpu if a.batch_per_gpu is not None else (preset["batch"] if pipeline else 30)
+    n_mb = a.microbatches if a.microbatches is not None else preset["microbatches"]
     strategy_name = a.mode
     pp_size = a.pp_size if a.mode != "ddp" else 1
     if a.mode == "pp":
         pp_size = world
-    def make_strategy(hip_graph: bool):
-        cfg = TrainConfig(strategy=strategy_name, batch_size=B, impl=a.impl, dtype=a.dtype,
-                          bucket_mb=a.bucket_mb, zero1=a.zero1, hip_graph=hip_graph,
-                          num_microbatches=a.microbatches, schedule=a.schedule, pp_size=pp_size,
-                          split_points=default_split_points(max(pp_size, 1)), profile=a.profile,
+    if a.split_points is not None:
+        split = a.split_points
+    elif pipeline and preset["split"] == "auto":
+        split = ["auto"]
+    else:
+        split = default_split_points(max(pp_size, 1))
+
+    def make_strategy(bucket_mb: float):
+        cfg = TrainConfig(strategy=strategy_name, batch_size=B, dtype=a.dtype,
+                          bucket_mb=bucket_mb, zero1=a.zero1, hip_graph=not a.no_graph,
+                          num_microbatches=n_mb, schedule=a.schedule, pp_size=pp_size,
+                          split_points=split, profile=a.profile,
                           sync_buffers=a.sync_buffers, num_workers=0,
                           **({} if a.grad_phases is None else {"grad_phases": a.grad_phases}),
                           **({} if a.grad_sync is None else {"grad_sync": a.grad_sync}))
         return build_strategy(cfg, ctx)
 
-    strat = make_strategy(not a.no_graph)
+    def fail(stage: str, e: BaseException) -> None:
+        # A failed capture / step is a failed run.  Peers of a failing rank sit in collectives: leave at once
+        # (the launcher tears the job down) instead of joining a barrier that can never complete.
+        traceback.print_exc()
+        print(f"[rank {ctx.rank}] bench.py FAILED during {stage}: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(3)
+
+    try:
+        strat = make_strategy(a.bucket_mb)
+    except BaseException as e:      # noqa: BLE001
+        fail("strategy construction", e)
     dp = strat.dp_size
 
     g = torch.Generator().manual_seed(1234 + ctx.rank)
@@ -95,67 +140,111 @@ def main() -> None:
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
 
+    def run_steps(s, n, first=0):
+        for i in range(first, first + n):
+            x, y = pool[i % len(pool)]
+            s.train_step(x, y, B)
+
+    def timed(s, n):
+        """(wall seconds incl. device drain, host seconds to issue) of n steps, barrier-bracketed."""
+        sync()
+        t0 = time.perf_counter()
+        run_steps(s, n)
+        host = time.perf_counter() - t0          # host time to ISSUE the steps (no device wait in the loop)
+        sync()
+        return time.perf_counter() - t0, host
+
+    def max_over_ranks(v: float) -> float:
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        if comm.is_dist() and world > 1:
+            comm.all_reduce(t, "max")
+        return float(t.item())
+
     # Priming (set-up, never timed, independent of --warmup): RCCL communicator creation, allocator growth
     # and the hipGraph capture (2 eager steps + the capturing step) must not land in the timed region even
     # when the driver asks for fewer warm-up steps than that.
     PRIME = 3
     strat.model.train()
-    failure = None
     try:
-        for i in range(PRIME + a.warmup):
-            x, y = pool[i % len(pool)]
-            strat.train_step(x, y, B)
-        graph_mode = "off" if a.no_graph else "hipGraph"
-    except Exception as e:      # noqa: BLE001 - e.g. a capture refused by the runtime: measure the eager path instead
-        if a.no_graph:
-            raise
-        failure = e
-    if world > 1 and not a.no_graph:          # every rank takes the same path (a capture failure is symmetric)
-        flag = torch.tensor([0.0 if failure is None else 1.0], device=dev)
-        comm.all_reduce(flag, "max")
-        if flag.item() > 0 and failure is None:
-            failure = RuntimeError("another rank failed in the hipGraph path")
-    if failure is not None:
-        e = failure
-        print(f"[rank {ctx.rank}] hipGraph path failed during warm-up ({type(e).__name__}: {e}); "
-              f"falling back to eager launches", file=sys.stderr, flush=True)
+        run_steps(strat, PRIME + a.warmup)
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
-        os.environ["DDL_NATIVE_REDUCER"] = "0"      # most conservative path: eager launches, Python bucket reducer
-        strat = make_strategy(False)
-        strat.model.train()
-        for i in range(PRIME + a.warmup):
-            x, y = pool[i % len(pool)]
-            strat.train_step(x, y, B)
-        graph_mode = "eager (fallback)"
+    except BaseException as e:      # noqa: BLE001
+        fail("warm-up / hipGraph capture", e)
+    graph_mode = "off" if (a.no_graph or dev.type != "cuda") else "hipGraph"
+
     # The per-step compute / RCCL split costs ~1 % (timing events on every stream), so the profiler is paused for
     # the timed steps and the split is measured on extra steps behind them ("profile_steps" in the JSON).
     strat.profiler.reset()
     if a.profile:
         strat.profiler.set_enabled(False)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        x, y = pool[i % len(pool)]
-        strat.train_step(x, y, B)
-    host_dt = time.perf_counter() - t0          # host time to ISSUE the steps (no device wait in the loop)
-    sync()
-    dt = time.perf_counter() - t0
+    try:
+        dt, host_dt = timed(strat, a.steps)
+    except BaseException as e:      # noqa: BLE001
+        fail("the timed steps", e)
+    dt = max_over_ranks(dt)
+    host_ms = max_over_ranks(host_dt / a.steps * 1e3)
+    step_ms = dt / a.steps * 1e3
+    host_bound = host_ms > 0.8 * step_ms
+
+    profile = None
     if a.profile:
         strat.profiler.set_enabled(True)
-        for i in range(min(a.steps, 20)):
-            x, y = pool[i % len(pool)]
-            strat.train_step(x, y, B)
+        run_steps(strat, min(a.steps, 20))
         sync()
+        profile = strat.profiler.summary()
+        strat.profiler.set_enabled(False)
+        n_prof = profile.pop("steps")
+        # the slowest rank sets the step: report every span as the maximum over ranks
+        keys = sorted(k for k in profile if k.endswith("_ms_per_step"))
+        if comm.is_dist() and world > 1:
+            t = torch.tensor([profile.get(k, 0.0) for k in keys], dtype=torch.float64, device=dev)
+            comm.all_reduce(t, "max")
+            profile = {k: float(v) for k, v in zip(keys, t.tolist())}
+        step_p = profile.get("step_ms_per_step", 0.0)
+        if step_p > 0:
+            exposed = profile.get("exposed_comm_ms_per_step", 0.0) + profile.get("p2p_wait_ms_per_step", 0.0)
+            busy = profile.get("rccl_ms_per_step", 0.0) + profile.get("p2p_ms_per_step", 0.0)
+            profile["comm_busy_fraction"] = busy / step_p
+            profile["comm_exposed_fraction"] = exposed / step_p
+            profile["compute_fraction"] = max(0.0, 1.0 - exposed / step_p)
+        profile["host_issue_ms_per_step"] = host_ms
+        profile["profile_steps"] = n_prof
+        profile["reduced_over_ranks"] = "max"
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if comm.is_dist() and world > 1:
-        comm.all_reduce(t, "max")
-    dt = float(t.item())
+    # ---- tuning data behind the timed region (multi-rank runs; `--ab on` to rehearse with one rank) ----------
+    ab = a.ab == "on" or (a.ab == "auto" and world > 1)
+    engine = getattr(strat, "dp", None)
+    grad_sync_ab, bucket_sweep = None, None
+    if ab and engine is not None and not engine.single and not a.zero1:
+        try:
+            grad_sync_ab = {}
+            chosen = engine.grad_sync
+            for mode in ("rs_ag", "allreduce"):
+                engine.set_grad_sync(mode)
+                run_steps(strat, 3)
+                t, _ = timed(strat, a.ab_steps)
+                grad_sync_ab[mode] = round(max_over_ranks(t) / a.ab_steps * 1e3, 3)
+            engine.set_grad_sync(chosen)
+            if a.mode == "ddp":
+                bucket_sweep = {str(a.bucket_mb): round(step_ms, 3)}
+                for mb in (2.0, 32.0):
+                    if mb == a.bucket_mb:
+                        continue
+                    s2 = make_strategy(mb)
+                    s2.model.train()
+                    s2.profiler.set_enabled(False)
+                    run_steps(s2, PRIME + 3)
+                    t, _ = timed(s2, a.ab_steps)
+                    bucket_sweep[str(mb)] = round(max_over_ranks(t) / a.ab_steps * 1e3, 3)
+                    del s2
+        except BaseException as e:      # noqa: BLE001 - the headline is measured; a failed extra must not lose it on THIS rank
+            print(f"[rank {ctx.rank}] tuning extras failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            grad_sync_ab = grad_sync_ab or {"error": f"{type(e).__name__}: {e}"}
+
     global_batch = B * dp
     value = global_batch * a.steps / dt
     base_key = "single" if (a.mode == "ddp" and world == 1) else a.mode
-    impl = type(strat.model).__name__
     out = {
         "metric": "samples/sec (whole job), DenseNet-121 training",
         "value": round(value, 2),
@@ -163,12 +252,14 @@ def main() -> None:
         "n_gpus": world,
         "steps": a.steps,
         "warmup": a.warmup,
-        "ms_per_step": round(dt / a.steps * 1e3, 3),
+        "ms_per_step": round(step_ms, 3),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": round(value / BASELINE[base_key], 2),
         "dtype": a.dtype,
         "data": "synthetic uint8 3x224x224 images generated on device, random-init weights",
+        "host_issue_ms_per_step": round(host_ms, 3),
+        "host_bound": bool(host_bound),
         "config": {
             "model": "DenseNet-121 (5-class head, 6,958,981 params)",
             "global_batch": global_batch,
@@ -179,20 +270,29 @@ def main() -> None:
             "parallelism": (f"dp{dp}" if a.mode == "ddp" else
                             f"pp{pp_size}" if a.mode == "pp" else f"dp{dp}xpp{pp_size}"),
             "baseline": f"{base_key} {BASELINE[base_key]} samples/s (BASELINE.md sec. 2)",
-            "impl": impl,
+            "impl": type(strat.model).__name__,
             "launch": graph_mode,
             "grad_sync": ("zero1 rs+ag(params)" if a.zero1 else
-                          "bucketed all-reduce" if getattr(getattr(strat, "dp", None), "grad_sync", "") == "allreduce"
+                          "bucketed all-reduce" if getattr(engine, "grad_sync", "") == "allreduce"
                           else "bucketed reduce-scatter + all-gather"),
-            "reducer": ("native" if getattr(getattr(strat, "dp", None), "_native", None) is not None else "python"),
-            "host_issue_ms_per_step": round(host_dt / a.steps * 1e3, 3),
+            "bucket_mb": a.bucket_mb,
+            "reducer": ("native" if getattr(engine, "_native", None) is not None else "python"),
+            "host_issue_ms_per_step": round(host_ms, 3),
             "peak_mem_gib": (round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2) if dev.type == "cuda" else None),
         },
     }
-    if a.profile:
-        out["profile"] = {k: (round(v, 4) if isinstance(v, float) else v)
-                          for k, v in strat.profiler.summary().items()}
-        out["profile"]["profile_steps"] = out["profile"].pop("steps")     # extra steps behind the timed region
+    if pipeline:
+        out["config"].update(preset=a.preset, microbatches=n_mb, schedule=a.schedule,
+                             split_points=list(getattr(strat, "split_points", split)))
+    if profile is not None:
+        out["profile"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in profile.items()}
+    if grad_sync_ab is not None:
+        out["grad_sync_ab"] = grad_sync_ab          # ms/step of the same captured step with either collective form
+    if bucket_sweep is not None:
+        out["bucket_mb_sweep"] = bucket_sweep       # ms/step per bucket size (MiB)
+    if host_bound and ctx.rank == 0:
+        print(f"WARNING: host-bound run - issuing a step took {host_ms:.2f} ms of the {step_ms:.2f} ms step "
+              f"(> 80 %); the GPUs wait for the host", file=sys.stderr, flush=True)
     if ctx.rank == 0:
         print(json.dumps(out), flush=True)
     sync()

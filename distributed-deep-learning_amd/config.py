@@ -51,14 +51,15 @@ class TrainConfig:
     seed: Optional[int] = None          # reference defines set_seed but never calls it
     max_steps: int = 0                  # >0: stop each epoch after this many steps (smoke runs)
     # ---- model ---------------------------------------------------------------
-    impl: str = "auto"                  # auto | native | torch   (auto: native on GPU, torch on CPU)
     dtype: str = "fp32"                 # fp32 (reference parity) | bf16 (mixed: bf16 MFMA inputs)
     hip_graph: bool = True              # capture the native train step into a hipGraph
     pretrained: Optional[str] = field(default_factory=lambda: os.environ.get("DDL_PRETRAINED") or None)
     #   ^ torchvision densenet121 state-dict file (reference: weights=IMAGENET1K_V1, single.py:297)
     # ---- data parallel -------------------------------------------------------
     bucket_mb: float = 8.0              # gradient bucket size (MiB); sized for xGMI, not NVSwitch
-    grad_sync: str = "allreduce"        # allreduce (one RCCL kernel per bucket) | rs_ag (reduce-scatter + all-gather; forced by --zero1)
+    grad_sync: str = "rs_ag"            # rs_ag (reduce-scatter + all-gather: both run directly over all 7 xGMI links of a
+    #                                     fully connected node; the north-star form, also what --zero1 needs) | allreduce
+    #                                     (one RCCL launch per bucket).  bench.py at W>1 times both ("grad_sync_ab").
     zero1: bool = False                 # shard the Adam step over the dp group (RS grads, AG params)
     sync_buffers: str = "forward"       # forward (DDP parity) | epoch | off
     grad_phases: str = "denseblock3,denseblock2"   # units that open a new backward graph phase (DP overlap)

@@ -66,6 +66,7 @@ void adam_step(at::Tensor p, at::Tensor g, at::Tensor m, at::Tensor v, at::Tenso
 void register_conv_ops(pybind11::module_& m);   // conv_bindings.cpp
 void register_stem_ops(pybind11::module_& m);   // stem_bindings.cpp
 void register_reducer(pybind11::module_& m);    // reducer.cpp
+void register_p2p(pybind11::module_& m);        // p2p.cpp
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "hand-written gfx950 (MI355X) kernels of the ddl framework";
@@ -75,4 +76,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   register_conv_ops(m);
   register_stem_ops(m);
   register_reducer(m);
+  register_p2p(m);
 }

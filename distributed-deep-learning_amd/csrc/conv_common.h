@@ -19,7 +19,7 @@ __device__ __forceinline__ void conv_fill_tables(const ConvGemmParams& p, bool a
         float k0, k1, k2;
         if (p.fk.acc != nullptr) {
           float dg, db;
-          fused_k(p.fk, c, kStatReplicas, 1.0 / kStatScale, k0, k1, k2, dg, db);
+          fused_k(p.fk, c, kStatReplicas, 1.0 / kGradStatScale, k0, k1, k2, dg, db);
           if (writer) { p.fk.dgamma[c] += dg; p.fk.dbeta[c] += db; }
         } else {
           k0 = p.a.s0[c]; k1 = p.a.s1[c]; k2 = p.a.s2[c];
@@ -158,7 +158,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16 (&
         for (int g = 0; g < RG; ++g) s += red[(which * RG + g) * BN + cc];
         if ((KIND == 0 || KIND == 2) && p.bn.acc_out != nullptr) {   // fused statistics: fixed-point integer atomics
           __hip_atomic_fetch_add(p.bn.acc_out + (long)(2 * (tile_x & (kStatReplicas - 1)) + which) * p.bn.acc_out_ld + n0 + cc,
-                                 __double2ll_rn((double)s * kStatScale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                 __double2ll_rn((double)s * (KIND == 2 ? kGradStatScale : kStatScale)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
           p.stats_out[((long)tile_x * 2 + which) * p.N + n0 + cc] = s;
         }

@@ -37,7 +37,12 @@ struct RowSrc {
 // resolution per addend - a channel's sum of squares over 1.6M pixels (batch 512 on the 56x56 maps) stays in range
 // up to an rms activation of ~146, far above anything a batch-normalised network produces; the per-tile partials
 // that are added are fp32 sums of <= 128 rows, so the fixed-point rounding is below their own rounding.
-constexpr double kStatScale = 268435456.0;      // 2^28: fixed-point scale of the accumulators
+constexpr double kStatScale = 268435456.0;      // 2^28: fixed-point scale of the FORWARD accumulators
+// The backward (sum g, sum g*h) accumulators of FusedK hold gradient sums: per-tile partials are routinely below
+// 1e-6 in the early blocks, where a 2^-28 quantum would round most of their bits away.  They get their own
+// scale: 2^48 -> 3.6e-15 absolute resolution, |sum| < 32768 (a mean-reduced loss keeps every gradient sum
+// orders of magnitude below that; a partial beyond the range saturates the conversion, it cannot wrap).
+constexpr double kGradStatScale = 281474976710656.0;   // 2^48
 constexpr int kStatReplicas = 8;
 // epilogue transposition image: row stride in floats (rocprofv3: 5-10 % of the LDS-active cycles are bank
 // conflicts at 36, 18 % at 40; kernel times are the same either way)

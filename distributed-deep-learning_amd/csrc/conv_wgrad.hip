@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(256) wgrad1x1_kernel(const WgradParams p) {
     float* kt = smem;                    // [3][128], dead before the first store_step
     if (tid < 128) {
       float k0 = 0.f, k1 = 0.f, k2 = 0.f, dg, db;
-      if (n0 + tid < p.N) fused_k(p.fk, n0 + tid, kStatReplicas, 1.0 / kStatScale, k0, k1, k2, dg, db);
+      if (n0 + tid < p.N) fused_k(p.fk, n0 + tid, kStatReplicas, 1.0 / kGradStatScale, k0, k1, k2, dg, db);
       kt[tid] = k0; kt[128 + tid] = k1; kt[256 + tid] = k2;
     }
     __syncthreads();

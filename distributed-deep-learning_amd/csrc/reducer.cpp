@@ -138,6 +138,13 @@ class BucketReducer {
   }
 
   void set_timing(bool on) { timing_ = on; }          // RCCL span events on / off (StepProfiler.set_enabled)
+  // per-bucket collective: one in-place all-reduce, or reduce-scatter + all-gather.  The buckets are plain arena
+  // ranges and the collectives stay outside the captured graphs, so the form can change between two steps
+  // (bench.py measures both on the same captured step: "grad_sync_ab")
+  void set_allreduce(bool on) {
+    TORCH_CHECK(!zero1_ || !on, "ZeRO-1 needs the scattered form");
+    allreduce_ = on;
+  }
   int64_t launches() const { return launches_; }
 
  private:
@@ -177,5 +184,6 @@ void register_reducer(pybind11::module_& m) {
       .def("finish", &BucketReducer::finish)
       .def("drain_ms", &BucketReducer::drain_ms)
       .def("set_timing", &BucketReducer::set_timing)
+      .def("set_allreduce", &BucketReducer::set_allreduce)
       .def_property_readonly("launches", &BucketReducer::launches);
 }

@@ -1,4 +1,4 @@
-"""Model factory: the portable PyTorch definition or the native gfx950 engine."""
+"""Model factory: the native gfx950 engine on a GPU, the portable PyTorch definition on the CPU."""
 from __future__ import annotations
 
 from typing import Sequence
@@ -9,23 +9,16 @@ from .densenet import (UNIT_NAMES, DenseNetStage, build_stage, default_split_poi
                        stage_units)
 
 
-def resolve_impl(impl: str, device) -> str:
-    device = torch.device(device)
-    if impl == "auto":
-        return "native" if device.type == "cuda" else "torch"
-    if impl == "native" and device.type != "cuda":
-        raise ValueError("impl=native needs a GPU (the engine is HIP kernels); use impl=torch on CPU")
-    return impl
-
-
-def create_stage(units: Sequence[str], device, impl: str = "auto", num_classes: int = 5,
-                 dtype: str = "fp32", pretrained: str = None, **native_kw) -> torch.nn.Module:
+def create_stage(units: Sequence[str], device, num_classes: int = 5, dtype: str = "fp32",
+                 pretrained: str = None, **native_kw) -> torch.nn.Module:
     """A contiguous run of DenseNet-121 units on ``device``.
 
-    ``impl='torch'``: plain PyTorch ops (CPU plumbing path; numerics oracle).
-    ``impl='native'``: the hand-written HIP engine (NHWC, flat arena, fused BN/ReLU/conv)."""
-    impl = resolve_impl(impl, device)
-    if impl == "torch":
+    The device decides the implementation - there is no user-selectable backend: on a GPU a stage IS the
+    hand-written HIP engine (NHWC, flat arena, fused BN/ReLU/conv; ``NativeDenseNetStage``); on the CPU
+    (gloo plumbing tests, checkpoint tooling) it is the plain-PyTorch definition, which is also the fp32
+    numerics oracle the GPU tests instantiate directly (``DenseNetStage(...).to(device)``)."""
+    device = torch.device(device)
+    if device.type != "cuda":
         stage = DenseNetStage(units, num_classes).to(device)
     else:
         from .native_densenet import NativeDenseNetStage

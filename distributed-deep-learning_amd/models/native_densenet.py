@@ -134,7 +134,12 @@ class _BlockFn(torch.autograd.Function):
         L, Cf = unit.num_layers, unit.c_out
         M = B * H * W
         f32 = dict(dtype=torch.float32, device=buf.device)
-        dbuf = dbuf.contiguous()
+        # The 1x1 data-gradient epilogues accumulate into dBuf IN PLACE.  That is only legitimate on a tensor this
+        # engine produced itself for exactly this consumer (the following transition / head backward); any other
+        # incoming gradient - a pipeline receive slot, a user hook's tensor - is copied first (autograd contract).
+        owned = dbuf.is_contiguous() and dbuf.data_ptr() == unit.stage._owned_grad_ptr
+        dbuf = dbuf if owned else dbuf.clone(memory_format=torch.contiguous_format)
+        unit.stage._owned_grad_ptr = 0
         d2d = dbuf.view(M, Cf)
         buf2d = buf.view(M, Cf)
         nq = torch.zeros(Cf, **f32)           # deferred terms: dX = dBuf + nq * x + np
@@ -146,8 +151,8 @@ class _BlockFn(torch.autograd.Function):
         # them while the next layer's 3x3 dgrad runs.  (Measured at batch 30: 1 buffer 11.65 ms/step,
         # 2: 9.31, 3: 9.53, 4: 9.68, 6: 10.03 - a weight-gradient stream that lags further reads
         # operands that have left the L2.)
-        side = unit.stage.side_stream if unit.stage.overlap_wgrad else None
         main = torch.cuda.current_stream(buf.device)
+        side = unit.stage.fork(main) if unit.stage.overlap_wgrad else None
         NB = unit.stage.g2_bufs
         k = torch.empty(NB, 3, MID, **f32)
         g2 = torch.empty(NB, M, MID, **f32)
@@ -209,7 +214,7 @@ class _BlockFn(torch.autograd.Function):
                                 **kf, **kg)
             ext.bn_bwd_prep(st1, float(M), stats[0], stats[2], sc1[l], lay.gg1, lay.gb1, None, nq, np_, C, 1)
         if side is not None:
-            main.wait_stream(side)
+            unit.stage.join(main, side)
         dx = torch.empty(B, H, W, C0, **f32)
         ext.rows_op(4, M, d2d[:, :C0], buf2d[:, :C0], nq, np_, dx.view(M, C0), H, W, False)
         unit.stage._unit_grads_ready(unit)
@@ -315,6 +320,7 @@ class _TransitionFn(torch.autograd.Function):
         ext.bn_bwd_prep(st, float(M), stats[0], stats[2], ss[0], unit.gg, unit.gb, k[0], k[1], k[2], C, 0)
         ext.rows_op(4, M, d2d, buf2d, k[1], k[2], d2d, H, W, False)     # dX = sc*g + k1*x + k2
         unit.stage._unit_grads_ready(unit)
+        unit.stage._owned_grad_ptr = dbuf.data_ptr()       # fresh tensor, single consumer: may be updated in place
         return dbuf, None, None, None
 
 
@@ -378,6 +384,7 @@ class _HeadFn(torch.autograd.Function):
         ext.bn_bwd_prep(st, float(M), stats[0], stats[2], ss[0], unit.gg, unit.gb, k[0], k[1], k[2], C, 0)
         ext.rows_op(4, M, d2d, buf2d, k[1], k[2], d2d, H, W, False)
         unit.stage._unit_grads_ready(unit)
+        unit.stage._owned_grad_ptr = dbuf.data_ptr()
         return dbuf, None, None, None
 
 
@@ -505,6 +512,8 @@ class NativeDenseNetStage(nn.Module):
         self.anchor = torch.zeros(1, device=device, requires_grad=True)   # keeps every unit in the graph
         self.side_stream = torch.cuda.Stream(device)
         self.overlap_wgrad = True
+        self._fork_origin = None          # origin stream of the open side-stream fork (see ``fork``)
+        self._owned_grad_ptr = 0          # data_ptr of the gradient a transition / head backward just produced
         self.ones = torch.ones(1024, device=device)
         self._grad_ready_cb = None
         self.unit_objs = []
@@ -570,6 +579,29 @@ class NativeDenseNetStage(nn.Module):
 
     def bv(self, fqn: str) -> torch.Tensor:
         return self._buffers_by_name[fqn]
+
+    # ---- side-stream discipline ------------------------------------------------------------
+    # Ending a HIP stream capture whose nested fork rejoins the origin only THROUGH an intermediate stream
+    # crashes the runtime (SIGSEGV in capture_end, round 1).  Rule: a side stream is forked from the origin
+    # stream only, and joined into the origin directly.  ``fork`` / ``join`` enforce it; ``assert_joined`` is
+    # called by the capture code before a capture ends.
+    def fork(self, origin: "torch.cuda.Stream") -> "torch.cuda.Stream":
+        if origin == self.side_stream or self._fork_origin is not None:
+            raise RuntimeError("nested stream fork: the weight-gradient side stream must be forked from the origin "
+                               "stream and joined into it directly (a nested fork crashes hipStreamEndCapture)")
+        self._fork_origin = origin
+        return self.side_stream
+
+    def join(self, origin: "torch.cuda.Stream", side: "torch.cuda.Stream") -> None:
+        if self._fork_origin is None or origin != self._fork_origin or side != self.side_stream:
+            raise RuntimeError("stream join does not match the open fork: join the side stream into its origin directly")
+        origin.wait_stream(side)
+        self._fork_origin = None
+
+    def assert_joined(self) -> None:
+        if self._fork_origin is not None:
+            self._fork_origin = None
+            raise RuntimeError("a forked side stream was not joined into its origin stream before the capture ended")
 
     # ---- DP integration ------------------------------------------------------------------
     def set_grad_ready_callback(self, cb) -> None:

@@ -20,10 +20,15 @@ ddp_n_pp.py:139 ``DDP(stage_mod, process_group=dp)``):
                                          last micro-batch only (one sync per step per stage)
   =====================================  ==================================================
 
-Bucket size: 8 MiB default.  A ring over xGMI is bound by ONE 153 GB/s link per GPU, so
-large buckets buy nothing beyond amortising the ~10-20 us RCCL launch; small enough buckets
-let the first reduce start while most of backward is still to run (DenseNet-121 = 27.8 MB ->
-4 buckets).
+Per-bucket collective: ``rs_ag`` (default) = in-place reduce-scatter(AVG) + all-gather of the arena range - on a
+fully connected xGMI node both halves run directly over all 7 links of a GPU; ``allreduce`` = one RCCL launch
+per bucket.  Which one wins at a given world size is a measurement, not a belief: the form can be switched
+between two steps (``set_grad_sync``; the collectives live outside the captured graphs) and ``bench.py`` at
+W > 1 times both on the same captured step (``grad_sync_ab`` in its JSON) together with two more bucket sizes.
+
+Bucket size: 8 MiB default (DenseNet-121 = 27.8 MB -> 4 buckets, cut at the backward-phase boundaries): small
+enough that the first bucket leaves while most of the backward pass is still to run, large enough to amortise
+the ~10-20 us launch + fence cost of a collective.  ``bench.py`` sweeps 2 / 8 / 32 MiB behind its timed region.
 
 ZeRO-1 (``zero1=True``): stop after the reduce-scatter, let each rank run Adam on its 1/W
 shard (``FusedAdam(shard=...)``), then all-gather the *parameters* - same bytes on the wire,
@@ -113,6 +118,17 @@ class DataParallelEngine:
                     p.register_post_accumulate_grad_hook(self._make_hook(i))
             if hasattr(module, "set_grad_ready_callback"):
                 module.set_grad_ready_callback(self.param_ready)
+
+    def set_grad_sync(self, mode: str) -> None:
+        """Switch the per-bucket collective between two steps (``allreduce`` | ``rs_ag``).  Buckets are arena
+        ranges and collectives run outside the captured graphs, so nothing is re-captured."""
+        if mode not in ("allreduce", "rs_ag"):
+            raise ValueError(mode)
+        if self.zero1 and mode != "rs_ag":
+            raise ValueError("ZeRO-1 needs the scattered form (rs_ag)")
+        self.grad_sync = mode
+        if self._native is not None:
+            self._native.set_allreduce(mode == "allreduce")
 
     # ------------------------------------------------------------------ state sync
     def broadcast_state(self) -> None:

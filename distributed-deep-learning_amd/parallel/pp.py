@@ -15,15 +15,22 @@ What is different, MI355X-first:
     receive shapes come from the model's shape algebra (``recv_shape_fn``);
   * **1F1B** is the default schedule (BASELINE.json): at most ``S - stage`` micro-batches of
     activations are alive instead of all ``M``; GPipe is kept for parity runs;
-  * P2P is RCCL send/recv issued as *batched groups* per peer (forward-send fused with
-    backward-recv toward the next stage, backward-send fused with forward-recv toward the
-    previous one) - opposite-direction transfers between one pair must be one RCCL group or
-    they deadlock (SURVEY hard part 5); receives land in per-micro-batch pre-allocated slots;
+  * P2P goes through ``P2PChannel`` (parallel/p2p.py -> csrc/p2p.cpp): transfer groups are issued from a
+    dedicated P2P stream, sends are fenced behind the kernel that produced their payload, the receive of the
+    NEXT micro-batch is posted before the current one is computed (per-micro-batch slots, so the bytes cross
+    xGMI under compute), and the compute stream - never the host - waits per group (tickets).  Steady-state
+    1F1B transfers toward one peer stay ONE RCCL group (forward-send with backward-recv toward the next
+    stage, backward-send with forward-recv toward the previous one): issued as separate calls in different
+    orders on the two sides they deadlock (SURVEY hard part 5);
+  * every micro-batch forward / backward of a stage is its own hipGraph (``_GraphSet``);
   * gradients are scaled by 1/M (torch 2.6, which the reference pins, summed un-scaled
     per-micro-batch mean-loss gradients = M x the batch-mean gradient; documented deviation);
   * with a ``DataParallelEngine`` attached (hybrid), micro-batches 0..M-2 run under
     ``no_sync`` and the reducer is armed for the last backward only - one gradient sync per
-    step per stage, overlapped with that backward.
+    step per stage, overlapped with that backward (DDP arms its reducer for the last
+    micro-batch, ddp_n_pp.py:139 + torch stage.py:632-646).  Under hipGraphs that last backward is
+    captured as a CHAIN of graphs cut at the stage's backward phases (``forward_phased``), and the
+    gradient buckets a phase completed go to the comm stream before the next graph is enqueued.
 
 BatchNorm statistics are per micro-batch, exactly as in the reference.
 """
@@ -32,9 +39,8 @@ from __future__ import annotations
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
-import torch.distributed as dist
 
-from .. import comm
+from .p2p import P2PChannel, Transfer
 from ..utils.trace import trace_range
 
 
@@ -44,11 +50,30 @@ def split_sizes(batch: int, n: int) -> List[int]:
     return [base + (1 if i < rem else 0) for i in range(n)]
 
 
+def phase_segments(module, arena) -> List[List[int]]:
+    """Which arena segments (= gradient buckets) are complete after each backward phase of ``module``
+    (execution order: last units first).  Segments are cut at phase boundaries by construction
+    (``NativeDenseNetStage``: ``break_before``), so this is a static table."""
+    pending = [sum(1 for i in seg.slots if arena.params[i].requires_grad) for seg in arena.segments]
+    index = {n: i for i, n in enumerate(arena.names)}
+    out = []
+    for names in module.phase_param_names():
+        done = []
+        for n in names:
+            k = arena.slots[index[n]].segment
+            pending[k] -= 1
+            if pending[k] == 0:
+                done.append(k)
+        out.append(done)
+    return out
+
+
 class _GraphNode:
-    __slots__ = ("graph", "x", "t", "inp", "out", "loss")
+    __slots__ = ("graph", "x", "t", "inp", "out", "loss", "tail", "segments")
 
     def __init__(self) -> None:
         self.graph = self.x = self.t = self.inp = self.out = self.loss = None
+        self.tail, self.segments = [], []      # phased backward: later graphs + buckets completed per phase
 
 
 class _GraphSet:
@@ -87,7 +112,7 @@ class PipelineStage:
                  group=None, ranks: Optional[Sequence[int]] = None,
                  recv_shape_fn: Optional[Callable[[int], Tuple[int, ...]]] = None,
                  dtype: torch.dtype = torch.float32, dp_engine=None, hip_graph: bool = False,
-                 graph_warmup: int = 2) -> None:
+                 graph_warmup: int = 2, debug_sync: bool = False, profiler=None) -> None:
         self.module = module
         self.stage_index = stage_index
         self.num_stages = num_stages
@@ -101,6 +126,7 @@ class PipelineStage:
         self.recv_shape_fn = recv_shape_fn
         self.dtype = dtype
         self.dp_engine = dp_engine
+        self.chan = P2PChannel(group, self.device, debug_sync=debug_sync, profiler=profiler)
         self._act_slots = {}      # (mb_index, shape) -> recv buffer for forward activations
         self._grad_slots = {}     # (mb_index, shape) -> recv buffer for backward gradients
         # hipGraph capture of the per-micro-batch forward / backward (see ``_GraphSet``)
@@ -108,6 +134,12 @@ class PipelineStage:
         self.graph_warmup = graph_warmup
         self._graph_sets = {}     # signature of a step (micro-batch shapes, train/eval) -> _GraphSet
         self._gs: Optional[_GraphSet] = None
+        # hybrid under hipGraphs: the last micro-batch's backward runs as a chain of graphs cut at the module's
+        # backward phases, finished buckets go out between them (see the module docstring)
+        self.phased = (self.hip_graph and dp_engine is not None and not dp_engine.single
+                       and bool(getattr(module, "phase_starts", None)))
+        self.launch_trace: List[Tuple[str, int]] = []     # ("graph" | "bucket", index) of the last phased backward
+        self._cuts = {}
         self.reset()
 
     def reset(self) -> None:
@@ -115,8 +147,9 @@ class PipelineStage:
         self.outputs: dict = {}
         self.grads_in: dict = {}
         self.losses: dict = {}
+        self._cuts = {}
 
-    # ---- P2P op builders -----------------------------------------------------------------
+    # ---- P2P transfer builders -----------------------------------------------------------
     def _slot(self, table: dict, i: int, shape) -> torch.Tensor:
         key = (i, tuple(shape))
         buf = table.get(key)
@@ -125,30 +158,30 @@ class PipelineStage:
             table[key] = buf
         return buf
 
-    def fwd_recv_ops(self, i: int, mb: int) -> List[dist.P2POp]:
+    def fwd_recv(self, i: int, mb: int) -> List[Transfer]:
         if self.is_first:
             return []
         buf = self._slot(self._act_slots, i, self.recv_shape_fn(mb))
         self.inputs[i] = buf
-        return [dist.P2POp(dist.irecv, buf, self.prev_rank, self.group)]
+        return [(buf, self.prev_rank)]
 
-    def fwd_send_ops(self, i: int) -> List[dist.P2POp]:
+    def fwd_send(self, i: int) -> List[Transfer]:
         if self.is_last:
             return []
-        return [dist.P2POp(dist.isend, self.outputs[i].detach(), self.next_rank, self.group)]
+        return [(self.outputs[i].detach(), self.next_rank)]
 
-    def bwd_recv_ops(self, i: int) -> List[dist.P2POp]:
+    def bwd_recv(self, i: int) -> List[Transfer]:
         if self.is_last:
             return []
         buf = self._slot(self._grad_slots, i, self.outputs[i].shape)
         self.grads_in[i] = buf
-        return [dist.P2POp(dist.irecv, buf, self.next_rank, self.group)]
+        return [(buf, self.next_rank)]
 
-    def bwd_send_ops(self, i: int) -> List[dist.P2POp]:
+    def bwd_send(self, i: int) -> List[Transfer]:
         if self.is_first:
             return []
         g = self.inputs.pop(i)
-        return [dist.P2POp(dist.isend, g, self.prev_rank, self.group)]
+        return [(g, self.prev_rank)]
 
     # ---- hipGraph plumbing ---------------------------------------------------------------
     def begin_step(self, signature) -> None:
@@ -165,19 +198,20 @@ class PipelineStage:
         self._gs = gs if gs.active else None
 
     def forward(self, i: int, x: Optional[torch.Tensor], target: Optional[torch.Tensor],
-                loss_fn, train: bool) -> None:
+                loss_fn, train: bool, last: bool = False) -> None:
         with trace_range(f"Forward {i}"):          # the library's range names (schedules.py:757)
-            self._forward(i, x, target, loss_fn, train)
+            self._forward(i, x, target, loss_fn, train, last)
 
     def backward(self, i: int, scale: float, last: bool) -> None:
         with trace_range(f"Backward {i}"):         # schedules.py:785
             self._backward(i, scale, last)
 
     def _forward(self, i: int, x: Optional[torch.Tensor], target: Optional[torch.Tensor],
-                 loss_fn, train: bool) -> None:
+                 loss_fn, train: bool, last: bool) -> None:
         gs = self._gs
         if gs is None:
             return self._forward_eager(i, x, target, loss_fn, train)
+        phased = self.phased and train and last
         node = gs.fwd.get(i)
         if node is None:
             node = gs.fwd[i] = _GraphNode()
@@ -188,7 +222,7 @@ class PipelineStage:
             with torch.cuda.graph(node.graph, pool=gs.pool(), capture_error_mode="thread_local"):
                 if not self.is_first:
                     self.inputs[i] = inp_slot
-                self._forward_eager(i, node.x, node.t, loss_fn, train)
+                self._forward_eager(i, node.x, node.t, loss_fn, train, phased)
             node.inp, node.out, node.loss = self.inputs.get(i), self.outputs[i], self.losses.get(i)
         else:
             if node.x is not None:
@@ -208,16 +242,29 @@ class PipelineStage:
             return self._backward_eager(i, scale, last)
         dp = self.dp_engine
         node = gs.bwd.get(i)
+        mode = dict(pool=gs.pool(), capture_error_mode="thread_local")
         if node is None:
             node = gs.bwd[i] = _GraphNode()
             if dp is not None:
                 dp.arm(False)                      # no collectives inside a capture
             grad_slot = self.grads_in.get(i)
+            cuts = self._cuts.pop(i, None)         # phased forward of the last micro-batch (hybrid)
             node.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(node.graph, pool=gs.pool(), capture_error_mode="thread_local"):
+            with torch.cuda.graph(node.graph, **mode):
                 if grad_slot is not None:
                     self.grads_in[i] = grad_slot
-                self._backward_eager(i, scale, False, arm=False)
+                self._backward_eager(i, scale, False, arm=False, finish_input=not cuts)
+                self._check_joined()
+            if cuts:
+                for k, (y_mid, leaf) in enumerate(reversed(cuts)):        # one graph per earlier phase
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, **mode):
+                        y_mid.backward(leaf.grad)
+                        if k == len(cuts) - 1:
+                            self._finish_input(i)
+                        self._check_joined()
+                    node.tail.append(g)
+                node.segments = phase_segments(self.module, dp.arena)
             node.inp = self.inputs.get(i)          # gradient w.r.t. the stage input (sent upstream)
             node.out = self.outputs.get(i)
         else:
@@ -226,17 +273,33 @@ class PipelineStage:
                 self.outputs[i] = node.out
             else:
                 self.outputs.pop(i, None)
+        if dp is not None and last:
+            dp.arm(True)                           # the reducer counts from here: this is the step's last backward
+        self.launch_trace = []
         node.graph.replay()
+        self.launch_trace.append(("graph", 0))
+        for k, g in enumerate(node.tail):
+            for seg in node.segments[k]:           # buckets completed by the graph just enqueued
+                dp.segment_ready(seg)
+                self.launch_trace.append(("bucket", seg))
+            with trace_range(f"Backward {i} phase {k + 1}"):
+                g.replay()
+            self.launch_trace.append(("graph", k + 1))
         if not self.is_first:
             self.inputs[i] = node.inp
         else:
             self.inputs.pop(i, None)
-        if dp is not None and last:
-            dp.arm(True)                           # buckets are launched by finish_grad_sync()
+        # the buckets of the final phase (and everything, when the backward is one graph) are launched by
+        # the strategy's finish_grad_sync()
+
+    def _check_joined(self) -> None:
+        check = getattr(self.module, "assert_joined", None)     # native stage: forked streams are back in the origin
+        if check is not None:
+            check()
 
     # ---- compute -------------------------------------------------------------------------
     def _forward_eager(self, i: int, x: Optional[torch.Tensor], target: Optional[torch.Tensor],
-                       loss_fn, train: bool) -> None:
+                       loss_fn, train: bool, phased: bool = False) -> None:
         if self.is_first:
             inp = x
         else:
@@ -244,12 +307,23 @@ class PipelineStage:
             if train:
                 inp.requires_grad_(True)
             self.inputs[i] = inp
-        out = self.module(inp)
+        if phased:
+            out, self._cuts[i] = self.module.forward_phased(inp)
+        else:
+            out = self.module(inp)
         self.outputs[i] = out
         if self.is_last and loss_fn is not None:
             self.losses[i] = loss_fn(out, target)
 
-    def _backward_eager(self, i: int, scale: float, last: bool, arm: bool = True) -> None:
+    def _finish_input(self, i: int) -> None:
+        if not self.is_first:
+            inp = self.inputs[i]
+            self.inputs[i] = inp.grad
+            inp.grad = None
+        else:
+            self.inputs.pop(i, None)
+
+    def _backward_eager(self, i: int, scale: float, last: bool, arm: bool = True, finish_input: bool = True) -> None:
         dp = self.dp_engine
         if dp is not None and arm:
             dp.arm(last)
@@ -260,43 +334,8 @@ class PipelineStage:
         else:
             # the 1/M factor entered at the loss on the last stage and rides the chain rule back
             torch.autograd.backward(self.outputs.pop(i), grad_tensors=self.grads_in.pop(i))
-        if not self.is_first:
-            inp = self.inputs[i]
-            self.inputs[i] = inp.grad
-            inp.grad = None
-        else:
-            self.inputs.pop(i, None)
-
-
-class _StagedRecv:
-    """gloo (test transport) cannot move GPU tensors: receive into host memory, copy up on wait."""
-
-    def __init__(self, work, host: torch.Tensor, dev: torch.Tensor) -> None:
-        self.work, self.host, self.dev = work, host, dev
-
-    def wait(self) -> None:
-        self.work.wait()
-        self.dev.copy_(self.host)
-
-
-def _batch_p2p(ops: List[dist.P2POp]):
-    if not ops:
-        return []
-    if ops[0].tensor.is_cuda and comm.backend_of(ops[0].group) == "gloo":
-        works = []
-        for op in ops:
-            if op.op is dist.isend:
-                works.append(dist.isend(op.tensor.detach().cpu(), op.peer, group=op.group))
-            else:
-                host = torch.empty(op.tensor.shape, dtype=op.tensor.dtype)
-                works.append(_StagedRecv(dist.irecv(host, op.peer, group=op.group), host, op.tensor))
-        return works
-    return dist.batch_isend_irecv(ops)
-
-
-def _wait(works) -> None:
-    for w in works:
-        w.wait()
+        if finish_input:
+            self._finish_input(i)
 
 
 class _ScheduleBase:
@@ -341,7 +380,9 @@ class _ScheduleBase:
         st.begin_step((tuple(sizes), train, self.loss_fn is not None,
                        tuple(x.shape[1:]) if x is not None else None))
         self.order = []
+        self._sends: List[Optional[int]] = []
         self._run(xs, ts, sizes, train)
+        self._settle()
         out = None
         if st.is_last:
             out = torch.cat([st.outputs[i].detach() for i in range(self.n)], dim=0)
@@ -355,7 +396,7 @@ class _ScheduleBase:
     def _F(self, i, xs, ts, train):
         self.order.append(f"F{i}")
         tok = self.profiler.begin("compute") if self.profiler else None
-        self.stage.forward(i, xs[i], ts[i], self.loss_fn if train else None, train)
+        self.stage.forward(i, xs[i], ts[i], self.loss_fn if train else None, train, last=(i == self.n - 1))
         if tok is not None:
             self.profiler.end(tok)
 
@@ -367,16 +408,56 @@ class _ScheduleBase:
         if tok is not None:
             self.profiler.end(tok)
 
-    def _comm(self, ops, wait: bool = True):
-        if not ops:
-            return []
-        tok = self.profiler.begin("p2p_wait") if (self.profiler and wait) else None
-        works = _batch_p2p(ops)
-        if wait:
-            _wait(works)
+    def _post(self, sends=(), recvs=()):
+        """Issue one transfer group on the P2P channel; returns its ticket (None for an empty group)."""
+        return self.stage.chan.post(sends, recvs)
+
+    def _send(self, sends) -> None:
+        """A pure send group: nobody on this rank waits for it before the end of the step."""
+        self._sends.append(self._post(sends=sends))
+
+    def _await(self, ticket) -> None:
+        """The compute stream waits for a group whose payload it is about to read ("p2p_wait" = how long it
+        actually stalled there)."""
+        if ticket is None:
+            return
+        tok = self.profiler.begin("p2p_wait") if self.profiler else None
+        self.stage.chan.wait(ticket)
         if tok is not None:
             self.profiler.end(tok)
-        return works
+
+    def _settle(self) -> None:
+        """End of the step: the send buffers (graph outputs, gradient slots) are rewritten by the next step."""
+        for t in self._sends:
+            self.stage.chan.wait(t)
+        self._sends = []
+        self.stage.chan.drain()
+
+    def _forward_phase(self, xs, ts, sizes, train, count: int, first: int = 0) -> None:
+        """Forwards ``first .. first+count-1`` with the next activation's receive posted one micro-batch ahead
+        (double buffering through the per-micro-batch slots); every forward's output is sent on."""
+        st = self.stage
+        tickets = {}
+        if count > 0:
+            tickets[first] = self._post(recvs=st.fwd_recv(first, sizes[first]))
+        for i in range(first, first + count):
+            if i + 1 < first + count:
+                tickets[i + 1] = self._post(recvs=st.fwd_recv(i + 1, sizes[i + 1]))
+            self._await(tickets.pop(i))
+            self._F(i, xs, ts, train)
+            self._send(st.fwd_send(i))
+
+    def _backward_phase(self, first: int, count: int) -> None:
+        st = self.stage
+        tickets = {}
+        if count > 0:
+            tickets[first] = self._post(recvs=st.bwd_recv(first))
+        for i in range(first, first + count):
+            if i + 1 < first + count:
+                tickets[i + 1] = self._post(recvs=st.bwd_recv(i + 1))
+            self._await(tickets.pop(i))
+            self._B(i)
+            self._send(st.bwd_send(i))
 
     def _run(self, xs, ts, sizes, train):
         raise NotImplementedError
@@ -386,21 +467,9 @@ class ScheduleGPipe(_ScheduleBase):
     """Fill-drain: F0..F(M-1) then B0..B(M-1) (the reference's schedule, pp.py:140-144)."""
 
     def _run(self, xs, ts, sizes, train):
-        st = self.stage
-        sends = []
-        for i in range(self.n):
-            self._comm(st.fwd_recv_ops(i, sizes[i]))
-            self._F(i, xs, ts, train)
-            sends += self._comm(st.fwd_send_ops(i), wait=False)
-        _wait(sends)
-        if not train:
-            return
-        sends = []
-        for i in range(self.n):
-            self._comm(st.bwd_recv_ops(i))
-            self._B(i)
-            sends += self._comm(st.bwd_send_ops(i), wait=False)
-        _wait(sends)
+        self._forward_phase(xs, ts, sizes, train, self.n)
+        if train:
+            self._backward_phase(0, self.n)
 
 
 class Schedule1F1B(_ScheduleBase):
@@ -411,49 +480,40 @@ class Schedule1F1B(_ScheduleBase):
         st = self.stage
         n = self.n
         if not train:
-            sends = []
-            for i in range(n):
-                self._comm(st.fwd_recv_ops(i, sizes[i]))
-                self._F(i, xs, ts, False)
-                sends += self._comm(st.fwd_send_ops(i), wait=False)
-            _wait(sends)
+            self._forward_phase(xs, ts, sizes, False, n)
             return
         warmup = min(n, st.num_stages - st.stage_index)
-        f = b = 0
-        pending_send = []
-        fwd_sends: List[dist.P2POp] = []
-        for _ in range(warmup):
-            self._comm(st.fwd_recv_ops(f, sizes[f]))
+        # warm-up: like the forward phase, but the LAST warm-up activation is held back - it travels in one
+        # group with the first gradient receive (same peer, opposite directions)
+        tickets = {0: self._post(recvs=st.fwd_recv(0, sizes[0]))}
+        fwd_sends: List[Transfer] = []
+        for f in range(warmup):
+            if f + 1 < warmup:
+                tickets[f + 1] = self._post(recvs=st.fwd_recv(f + 1, sizes[f + 1]))
+            self._await(tickets.pop(f))
             self._F(f, xs, ts, True)
-            _wait(pending_send)
-            fwd_sends = st.fwd_send_ops(f)
+            fwd_sends = st.fwd_send(f)
             if f != warmup - 1:
-                pending_send = self._comm(fwd_sends, wait=False)
+                self._send(fwd_sends)
                 fwd_sends = []
-            f += 1
+        f, b = warmup, 0
         # steady state: 1B1F
         while True:
             # forward-send of the newest activation fused with the backward-recv (same peer: next)
-            self._comm(fwd_sends + st.bwd_recv_ops(b))
+            self._await(self._post(sends=fwd_sends, recvs=st.bwd_recv(b)))
             self._B(b)
-            bwd_sends = st.bwd_send_ops(b)
+            bwd_sends = st.bwd_send(b)
             b += 1
             if f == n:
                 break
             # backward-send fused with the next forward-recv (same peer: prev)
-            self._comm(bwd_sends + st.fwd_recv_ops(f, sizes[f]))
+            self._await(self._post(sends=bwd_sends, recvs=st.fwd_recv(f, sizes[f])))
             self._F(f, xs, ts, True)
-            fwd_sends = st.fwd_send_ops(f)
+            fwd_sends = st.fwd_send(f)
             f += 1
-        # cooldown: drain the remaining backwards
-        pending_send = self._comm(bwd_sends, wait=False)
-        while b < n:
-            self._comm(st.bwd_recv_ops(b))
-            self._B(b)
-            _wait(pending_send)
-            pending_send = self._comm(st.bwd_send_ops(b), wait=False)
-            b += 1
-        _wait(pending_send)
+        # cooldown: drain the remaining backwards (next gradient's receive posted one ahead)
+        self._send(bwd_sends)
+        self._backward_phase(b, n - b)
 
 
 SCHEDULES = {"gpipe": ScheduleGPipe, "1f1b": Schedule1F1B}

@@ -117,7 +117,7 @@ class SingleStrategy(Strategy):
 
     def __init__(self, cfg, ctx) -> None:
         super().__init__(cfg, ctx)
-        self.model = create_stage(UNIT_NAMES, self.device, cfg.impl, cfg.num_classes, cfg.dtype,
+        self.model = create_stage(UNIT_NAMES, self.device, cfg.num_classes, cfg.dtype,
                                   pretrained=cfg.pretrained)
         self.arena = _arena_for(self.model, self.device, cfg.bucket_mb, 1)
         self.optimizer = self._make_optimizer(self.arena)
@@ -126,7 +126,7 @@ class SingleStrategy(Strategy):
         # replayed as one hipGraph launch after two eager warm-up steps
         self._step = GraphedTrainStep(self.model, self.optimizer, None, self.profiler,
                                       enabled=cfg.hip_graph and self.device.type == "cuda")
-        self._eval = GraphedEvalStep(self.model, enabled=cfg.hip_graph and cfg.impl != "torch")
+        self._eval = GraphedEvalStep(self.model, enabled=cfg.hip_graph and self.device.type == "cuda")
 
     def train_step(self, x, y, batch_size):
         return self._step(x, y)
@@ -142,7 +142,7 @@ class DDPStrategy(Strategy):
 
     def __init__(self, cfg, ctx, group=None) -> None:
         super().__init__(cfg, ctx)
-        self.model = create_stage(UNIT_NAMES, self.device, cfg.impl, cfg.num_classes, cfg.dtype,
+        self.model = create_stage(UNIT_NAMES, self.device, cfg.num_classes, cfg.dtype,
                                   pretrained=cfg.pretrained, **self._native_kw(cfg, comm.get_world_size(group)))
         self.dp = DataParallelEngine(self.model, group=group, device=self.device, bucket_mb=cfg.bucket_mb,
                                      grad_sync=cfg.grad_sync, sync_buffers=cfg.sync_buffers,
@@ -154,11 +154,10 @@ class DDPStrategy(Strategy):
         self.is_logger = ctx.rank == 0
         self._step = GraphedTrainStep(self.model, self.optimizer, self.dp, self.profiler,
                                       enabled=cfg.hip_graph and self.device.type == "cuda")
-        self._eval = GraphedEvalStep(self.model, enabled=cfg.hip_graph and cfg.impl != "torch")
+        self._eval = GraphedEvalStep(self.model, enabled=cfg.hip_graph and self.device.type == "cuda")
 
-    @staticmethod
-    def _native_kw(cfg, world):
-        if cfg.impl == "torch":
+    def _native_kw(self, cfg, world):
+        if self.device.type != "cuda":
             return {}
         # phased backward graphs (utils/graph.py) only matter when there is something to overlap with
         phases = tuple(u for u in cfg.grad_phases.split(",") if u) if ((world > 1 or comm.force_collectives()) and cfg.hip_graph) else ()
@@ -191,15 +190,31 @@ class PPStrategy(Strategy):
         self.mesh = mesh
         S = mesh.pp_size
         self.stage_index = mesh.pp_index
-        units_per_stage = stage_units(cfg.split_points)
+        self.split_points = list(cfg.split_points)
+        self.unit_costs = None
+        if self.split_points == ["auto"]:
+            # balance the stages on measured per-unit forward+backward time at this run's micro-batch size
+            # (models/split.py); the reference's fixed split leaves 73 % of the work on stage 0
+            from .models.split import auto_split_points
+            self.split_points, self.unit_costs = auto_split_points(
+                S, self.device, max(cfg.batch_size // max(cfg.num_microbatches, 1), 1), cfg.image_size, cfg.dtype)
+            if ctx.rank == 0:
+                print(f"[pp] auto split for {S} stages: {self.split_points} "
+                      f"(unit costs {[round(c, 3) for c in self.unit_costs]})", flush=True)
+        units_per_stage = stage_units(self.split_points)
         if len(units_per_stage) != S:
-            raise ValueError(f"{len(cfg.split_points)} split points make {len(units_per_stage)} stages, "
+            raise ValueError(f"{len(self.split_points)} split points make {len(units_per_stage)} stages, "
                              f"but the pipeline group has {S} ranks")
         self.units = units_per_stage[self.stage_index]
-        nat = dict(bucket_mb=cfg.bucket_mb, dp_world=mesh.dp_size) if cfg.impl != "torch" else {}
-        self.model = create_stage(self.units, self.device, cfg.impl, cfg.num_classes, cfg.dtype,
-                                  pretrained=cfg.pretrained, **nat)
         hybrid = mesh.dp_size > 1
+        nat = {}
+        if self.device.type == "cuda":
+            # hybrid under hipGraphs: the last micro-batch's backward is cut at every dense block of the stage so
+            # that finished gradient buckets leave while the earlier blocks are still in backward (pp.py docstring)
+            phases = tuple(u for u in self.units if u.startswith("denseblock")) if (hybrid and cfg.hip_graph) else ()
+            nat = dict(bucket_mb=cfg.bucket_mb, dp_world=mesh.dp_size, grad_phases=phases)
+        self.model = create_stage(self.units, self.device, cfg.num_classes, cfg.dtype,
+                                  pretrained=cfg.pretrained, **nat)
         self.name = "ddpnpp" if hybrid else "pp"
         if hybrid:
             self.dp = DataParallelEngine(self.model, group=mesh.get_group("dp"), device=self.device,
@@ -236,7 +251,8 @@ class PPStrategy(Strategy):
         self.stage = PipelineStage(self.model, self.stage_index, S, self.device,
                                    group=mesh.get_group("pp"), ranks=mesh.pp_ranks,
                                    recv_shape_fn=recv_shape, dp_engine=self.dp,
-                                   hip_graph=cfg.hip_graph and native and self.device.type == "cuda")
+                                   hip_graph=cfg.hip_graph and native and self.device.type == "cuda",
+                                   debug_sync=cfg.debug_sync, profiler=self.profiler)
         sched = SCHEDULES[cfg.schedule]
         # two schedules over one stage, like the reference (pp.py:138-150): training (with loss)
         # and loss-less inference for evaluation under no_grad

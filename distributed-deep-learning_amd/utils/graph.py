@@ -75,20 +75,15 @@ class GraphedTrainStep:
         return res
 
     def _phase_segments(self):
-        """Which arena segments are complete after each backward phase (simulated once)."""
-        arena = self.dp.arena
-        pending = [sum(1 for i in seg.slots if arena.params[i].requires_grad) for seg in arena.segments]
-        index = {n: i for i, n in enumerate(arena.names)}
-        out = []
-        for names in self.model.phase_param_names():
-            done = []
-            for n in names:
-                k = arena.slots[index[n]].segment
-                pending[k] -= 1
-                if pending[k] == 0:
-                    done.append(k)
-            out.append(done)
-        return out
+        """Which arena segments are complete after each backward phase (static table)."""
+        from ..parallel.pp import phase_segments
+        return phase_segments(self.model, self.dp.arena)
+
+    def _check_joined(self) -> None:
+        """Inside a capture, before it ends: every forked stream is back in the origin (native_densenet.fork)."""
+        check = getattr(self.model, "assert_joined", None)
+        if check is not None:
+            check()
 
     def _capture(self, x, y) -> _Captured:
         c = _Captured()
@@ -109,6 +104,7 @@ class GraphedTrainStep:
                 c.loss, c.out, c.preds = self._fwd_bwd(c.x, c.y)
                 if not self.distributed:
                     self.optimizer.step()
+                self._check_joined()
         else:
             with torch.cuda.graph(c.graph, **mode):
                 self.optimizer.zero_grad()
@@ -116,10 +112,12 @@ class GraphedTrainStep:
                 loss, c.preds = ops.cross_entropy_with_preds(out, c.y)
                 loss.backward()
                 c.loss, c.out = loss.detach(), out.detach()
+                self._check_joined()
             for y_mid, leaf in reversed(cuts):          # one graph per earlier phase
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, **mode):
                     y_mid.backward(leaf.grad)
+                    self._check_joined()
                 c.tail_graphs.append(g)
             c.phase_segments = self._phase_segments()
         if hasattr(self.optimizer, "_host_step") and not self.distributed:

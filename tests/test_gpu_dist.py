@@ -23,7 +23,7 @@ def _ddp_worker(rank, world, zero1):
     torch.cuda.set_device(dev)
     torch.manual_seed(10 + rank)                       # ranks start different: broadcast must align them
     units = ("denseblock4", "head")
-    model = create_stage(units, dev, "native", 5, bucket_mb=1.0, dp_world=world)
+    model = create_stage(units, dev, 5, bucket_mb=1.0, dp_world=world)
     dp = DataParallelEngine(model, device=dev, bucket_mb=1.0, zero1=zero1)
     assert len(dp.arena.segments) > 2
     opt = FusedAdam(dp.arena, shard=(rank, world) if zero1 else None)
@@ -80,7 +80,7 @@ def _phased_graph_worker(rank, world):
     finals = []
     for graph in (True, False):
         torch.manual_seed(5)
-        cfg = TrainConfig(strategy="ddp", batch_size=4, impl="native", hip_graph=graph, bucket_mb=2.0,
+        cfg = TrainConfig(strategy="ddp", batch_size=4, hip_graph=graph, bucket_mb=2.0,
                           image_size=64, sync_buffers="forward")
         strat = DDPStrategy(cfg, ctx)
         if graph:
@@ -119,7 +119,7 @@ def _pp_worker(rank, world, schedule, graph):
     torch.cuda.set_device(dev)
     units = [("denseblock3", "transition3"), ("denseblock4", "head")]
     torch.manual_seed(0)                                # same seed everywhere: every rank can rebuild both stages
-    stages = [create_stage(u, dev, "native", 5) for u in units]
+    stages = [create_stage(u, dev, 5) for u in units]
     mine = stages[rank]
     n_mb, B = 2, 4
     g = torch.Generator().manual_seed(1)
@@ -162,6 +162,79 @@ def test_native_pipeline_two_stages_one_gpu(schedule, graph):
     run_distributed(_pp_worker, 2, schedule, graph, timeout=300)
 
 
+def _hybrid_overlap_worker(rank, world):
+    """2x2 hybrid on one GPU: under hipGraphs the last micro-batch's backward is a chain of graphs cut at the stage's
+    dense blocks, and the buckets a phase completed are handed to the reducer BEFORE the next graph is enqueued
+    (reference semantic: DDP arms its reducer for the last micro-batch, ddp_n_pp.py:139 + torch stage.py:632-646).
+    The graphed run must reproduce the eager (hook-driven) run and the serialised --debug-sync run."""
+    from ddl import comm
+    from ddl.config import TrainConfig
+    from ddl.trainer import build_strategy
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ctx = comm.CommContext(rank, world, 0, dev, "gloo")
+    finals = []
+    for graph, debug in ((True, False), (False, False), (False, True)):
+        torch.manual_seed(5)
+        cfg = TrainConfig(strategy="ddpnpp", batch_size=6, hip_graph=graph, bucket_mb=1.0, image_size=64, pp_size=2,
+                          num_microbatches=3, schedule="1f1b", debug_sync=debug)
+        strat = build_strategy(cfg, ctx)
+        strat.model.train()
+        g = torch.Generator().manual_seed(100 + strat.mesh.dp_index)
+        losses = []
+        for step in range(5):                                        # 2 eager warm-ups, capture, 2 replays
+            x = torch.randint(0, 256, (6, 3, 64, 64), dtype=torch.uint8, generator=g).to(dev)
+            y = torch.randint(0, 5, (6,), generator=g).to(dev)
+            res = strat.train_step(x if strat.needs_input else None, y if strat.needs_target else None, 6)
+            if res is not None:
+                losses.append(float(res[0]))
+        torch.cuda.synchronize()
+        if graph:
+            st = strat.stage
+            assert st.phased and strat.model.phase_starts, (st.phased, strat.model.phase_starts)
+            kinds = [k for k, _ in st.launch_trace]
+            assert kinds.count("graph") == len(strat.model.phase_starts) + 1
+            first_bucket, last_graph = kinds.index("bucket"), len(kinds) - 1 - kinds[::-1].index("graph")
+            assert first_bucket < last_graph, st.launch_trace      # a bucket left before the last backward graph
+        finals.append((strat.arena.flat_param.clone(), losses))
+        same = comm.all_gather_flat(strat.arena.flat_param.reshape(1, -1), strat.mesh.get_group("dp"))
+        torch.testing.assert_close(same[0], same[-1], rtol=0, atol=0)            # DP replicas identical
+    (pg, lg), (pe, le), (pd, ld) = finals
+    assert lg == le == ld, (lg, le, ld)                               # bit-deterministic engine: identical losses
+    torch.testing.assert_close(pg, pe, rtol=0, atol=0)
+    torch.testing.assert_close(pg, pd, rtol=0, atol=0)
+
+
+def test_hybrid_graphed_backward_overlaps_the_reduce_and_matches_eager():
+    run_distributed(_hybrid_overlap_worker, 4, timeout=420)
+
+
+def test_stream_fork_discipline_is_enforced():
+    """ending a capture whose nested fork rejoins through an intermediate stream crashed the
+    runtime.  The engine's fork/join helpers refuse a nested fork, a mismatched join and an unjoined capture."""
+    from ddl.models.native_densenet import NativeDenseNetStage
+    dev = torch.device("cuda", 0)
+    nat = NativeDenseNetStage(("denseblock4", "head"), 5, dev)
+    main = torch.cuda.current_stream(dev)
+    side = nat.fork(main)
+    with pytest.raises(RuntimeError, match="nested stream fork"):
+        nat.fork(main)                                               # second fork while one is open
+    with pytest.raises(RuntimeError, match="not joined"):
+        nat.assert_joined()                                          # what the capture code calls before capture_end
+    with pytest.raises(RuntimeError, match="nested stream fork"):
+        nat.fork(side)                                               # forking FROM the side stream
+    nat.fork(main)
+    with pytest.raises(RuntimeError, match="does not match"):
+        nat.join(torch.cuda.Stream(dev), side)                       # joining into a stream that is not the origin
+    nat.join(main, side)
+    nat.assert_joined()
+    # and a real backward leaves nothing open
+    nat.train()
+    x = torch.randn(2, 7, 7, 512, device=dev, requires_grad=True)
+    nat(x).sum().backward()
+    nat.assert_joined()
+
+
 def _torchrun(n, script, args, tmp_path):
     env = dict(os.environ, DDL_LOG_DIR=str(tmp_path / "logs"), DDL_CKPT_DIR=str(tmp_path / "ckpt"),
                DDL_DATA_DIR=str(tmp_path / "nodata"), OMP_NUM_THREADS="2", TORCHX_JOB_ID="job-gpu")
@@ -175,7 +248,7 @@ def _torchrun(n, script, args, tmp_path):
 
 
 SMALL = ["--epochs", "1", "--max-steps", "3", "--train-samples", "96", "--eval-samples", "48", "--num-workers", "0",
-         "--image-size", "64", "--impl", "native"]
+         "--image-size", "64"]
 
 
 def test_entry_scripts_on_gpu_shared_device(tmp_path):
@@ -263,7 +336,7 @@ def test_arena_layout_for_the_drivers_world_sizes(world):
     from ddl.models.densenet import UNIT_NAMES
     cfg = TrainConfig()
     phases = tuple(u for u in cfg.grad_phases.split(",") if u)
-    model = create_stage(UNIT_NAMES, torch.device("cuda", 0), "native", 5, bucket_mb=cfg.bucket_mb,
+    model = create_stage(UNIT_NAMES, torch.device("cuda", 0), 5, bucket_mb=cfg.bucket_mb,
                          dp_world=world, grad_phases=phases)
     arena = model.arena
     assert len(arena.segments) >= len(phases) + 1

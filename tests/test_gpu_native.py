@@ -454,7 +454,7 @@ def test_training_step_matches_reference_trajectory(dev):
     from ddl.config import TrainConfig
     from ddl.models.densenet import UNIT_NAMES
     from ddl.trainer import SingleStrategy
-    cfg = TrainConfig(strategy="single", batch_size=4, impl="native")
+    cfg = TrainConfig(strategy="single", batch_size=4)
     strat = SingleStrategy(cfg, comm.CommContext(0, 1, 0, dev, "none"))
     ref = _ref_stage(UNIT_NAMES, dev)
     strat.model.import_state_dict(ref.state_dict())
@@ -512,7 +512,7 @@ def test_bf16_mode_trains(dev):
     losses = {}
     sd = None
     for dt in ("fp32", "bf16"):
-        cfg = TrainConfig(strategy="single", batch_size=8, impl="native", dtype=dt)
+        cfg = TrainConfig(strategy="single", batch_size=8, dtype=dt)
         strat = SingleStrategy(cfg, comm.CommContext(0, 1, 0, dev, "none"))
         if sd is None:
             sd = {k: v.clone() for k, v in strat.model.export_state_dict().items()}
@@ -551,7 +551,7 @@ def test_odd_batches_and_image_sizes_train(dev, B, S):
     from ddl.config import TrainConfig
     from ddl.models.densenet import UNIT_NAMES
     from ddl.trainer import SingleStrategy
-    cfg = TrainConfig(strategy="single", batch_size=B, impl="native")
+    cfg = TrainConfig(strategy="single", batch_size=B)
     strat = SingleStrategy(cfg, comm.CommContext(0, 1, 0, dev, "none"))
     ref = _ref_stage(UNIT_NAMES, dev)
     strat.model.import_state_dict(ref.state_dict())

@@ -83,13 +83,13 @@ def test_pretrained_file_loading(tmp_path):
     assert "features.denseblock1.denselayer2.norm1.weight" in read_state_dict(path)
     assert normalise_keys({"a.denselayer3.conv.1.weight": torch.zeros(1)}).keys() == {"a.denselayer3.conv1.weight"}
     torch.manual_seed(1)
-    full = create_stage(UNIT_NAMES, "cpu", "torch", 5, pretrained=path)
+    full = create_stage(UNIT_NAMES, "cpu", 5, pretrained=path)
     ref = src.state_dict()
     for k, v in full.state_dict().items():
         if k.startswith("classifier."):
             assert tuple(v.shape) in ((5, 1024), (5,))
         else:
             torch.testing.assert_close(v, ref[k], rtol=0, atol=0)
-    stage = create_stage(("denseblock3", "transition3"), "cpu", "torch", 5, pretrained=path)
+    stage = create_stage(("denseblock3", "transition3"), "cpu", 5, pretrained=path)
     k = "features.denseblock3.denselayer7.conv1.weight"
     torch.testing.assert_close(stage.state_dict()[k], ref[k], rtol=0, atol=0)
