@@ -17,6 +17,8 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--bm", type=int, default=0)
 ap.add_argument("--bf16", action="store_true", help="bf16 MFMA inputs for the conv_gemm cases")
 ap.add_argument("--min-rows", type=int, default=64, help="wgrad: minimum pixel rows per workgroup")
+ap.add_argument("--sub", type=int, default=0, help="wgrad 1x1: force the sub-tile count (1, 3, 4) of the channel tiles")
+ap.add_argument("--defer", action="store_true", help="wgrad: queue the slab reductions (timed: the slab kernels alone)")
 ap.add_argument("--sweep", action="store_true", help="time every conv_gemm tile config per case")
 ap.add_argument("--cfg", type=int, default=-1, help="explicit conv_gemm tile config id (csrc/conv_gemm.hip)")
 a = ap.parse_args()
@@ -43,6 +45,7 @@ def timeit(fn, iters=a.iters):
 
 cases = []
 NCFG = 22
+WQ = dict(queue=ext.SlabQueue()) if a.defer else {}
 
 
 def case(name, flops):
@@ -114,15 +117,29 @@ for (blk, H, Cl, Cf) in [("b1", 56, 160, 256), ("b2", 28, 320, 512), ("b3", 14, 
     cases.append((f"{blk}_dgrad1x1_N{Cl}", 2.0 * M * Cl * 128, f4))
 
     def f5(M=M, g2=g2, h=h, k=k, buf=buf, Cl=Cl, sc=sc, sh=sh, gw1=gw1, H=H):
-        ext.conv_wgrad(g2, h, k[0], k[1], k[2], buf[:, :Cl], sc, sh, True, M, H, H, 1, gw1, a.min_rows)
+        ext.conv_wgrad(g2, h, k[0], k[1], k[2], buf[:, :Cl], sc, sh, True, M, H, H, 1, gw1, a.min_rows, force_sub=a.sub, **WQ)
     cases.append((f"{blk}_wgrad1x1_C{Cl}", 2.0 * M * Cl * 128, f5))
 
     def f6(M=M, dbuf=dbuf, buf=buf, Cl=Cl, ones=ones, sc=sc, sh=sh, h=h, gw2=gw2, H=H):
         ext.conv_wgrad(dbuf[:, Cl:Cl + 32], buf[:, Cl:Cl + 32], ones[:32], sc[:32], sh[:32], h, sc, sh, True, M, H, H,
-                       9, gw2, a.min_rows)
+                       9, gw2, a.min_rows, **WQ)
     cases.append((f"{blk}_wgrad3x3", 2.0 * M * 1152 * 32, f6))
 
+for (blk, H, Cl, Cf) in [("b1", 56, 64, 256), ("b1", 56, 96, 256), ("b1", 56, 224, 256), ("b2", 28, 160, 512), ("b2", 28, 480, 512),
+                         ("b3", 14, 288, 1024), ("b3", 14, 992, 1024), ("b4", 7, 544, 1024), ("b4", 7, 992, 1024)]:
+    M, buf = mk(H, Cl, Cf)
+    sc, sh = torch.rand(Cf, device=dev) + 0.5, torch.randn(Cf, device=dev)
+    h, g2 = torch.randn(M, 128, device=dev), torch.randn(M, 128, device=dev)
+    k = torch.randn(3, 128, device=dev) * 0.1
+    gw1 = torch.zeros(128, Cl, device=dev)
+
+    def f5x(M=M, g2=g2, h=h, k=k, buf=buf, Cl=Cl, sc=sc, sh=sh, gw1=gw1, H=H):
+        ext.conv_wgrad(g2, h, k[0], k[1], k[2], buf[:, :Cl], sc, sh, True, M, H, H, 1, gw1, a.min_rows, force_sub=a.sub, **WQ)
+    cases.append((f"{blk}_wgrad1x1_C{Cl}", 2.0 * M * Cl * 128, f5x))
+
 for name, flops, fn in cases:
+    if WQ:
+        WQ["queue"].flush()
     if a.only and a.only not in name:
         continue
     if a.sweep:

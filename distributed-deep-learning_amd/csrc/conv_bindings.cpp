@@ -237,11 +237,42 @@ void bn_acc_finalize(const at::Tensor& acc, int64_t c0, int64_t n, double count,
                               chan_rstd.data_ptr<float>(), cur_stream());
 }
 
-// dW[N, taps*C] += dO^T * rows(A)
+// Deferred slab reductions.  A weight-gradient kernel leaves S partial slabs; `dW += sum of slabs` of MANY weight
+// gradients (all layers of a dense block) runs as one launch when the queue is flushed, on the stream that is
+// current at that moment (the weight-gradient side stream).  The queue keeps the slab tensors alive until then.
+class SlabQueue {
+ public:
+  void push(at::Tensor slabs, at::Tensor dW, int64_t S, int64_t total4) {
+    entries_.push_back({std::move(slabs), std::move(dW), S, total4});
+  }
+  void flush() {
+    size_t i = 0;
+    while (i < entries_.size()) {
+      ddl::SlabReduceParams p{};
+      for (; i < entries_.size() && p.n < ddl::kMaxSlabEntries; ++i, ++p.n) {
+        const Entry& e = entries_[i];
+        p.e[p.n].slabs = e.slabs.data_ptr<float>();
+        p.e[p.n].dW = e.dW.data_ptr<float>();
+        p.e[p.n].S = (int)e.S;
+        p.e[p.n].total4 = (long)e.total4;
+      }
+      ddl::DeviceGuard guard(entries_[0].dW.device());
+      ddl::launch_slab_reduce_multi(p, cur_stream());
+    }
+    entries_.clear();
+  }
+  int64_t size() const { return (int64_t)entries_.size(); }
+
+ private:
+  struct Entry { at::Tensor slabs, dW; int64_t S, total4; };
+  std::vector<Entry> entries_;
+};
+
+// dW[N, taps*C] += dO^T * rows(A).  With a `queue` the slab reduction is deferred to queue.flush().
 void conv_wgrad(const at::Tensor& d0, const OptT& d1, const OptT& ds0, const OptT& ds1, const OptT& ds2,
                 const at::Tensor& a0, const OptT& as0, const OptT& as2, bool a_relu, int64_t M, int64_t H,
                 int64_t W, int64_t taps, at::Tensor dW, int64_t min_rows, const OptT& k_acc, const OptT& k_mean,
-                const OptT& k_rstd, const OptT& k_scale, double k_count) {
+                const OptT& k_rstd, const OptT& k_scale, double k_count, SlabQueue* queue, int64_t force_sub) {
   ddl::DeviceGuard guard(d0.device());
   const int64_t N = d0.size(1), C = a0.size(1);
   TORCH_CHECK(taps == 1 || taps == 9, "taps must be 1 or 9");
@@ -259,12 +290,30 @@ void conv_wgrad(const at::Tensor& d0, const OptT& d1, const OptT& ds0, const Opt
   TORCH_CHECK(dW.is_cuda() && dW.scalar_type() == at::kFloat && dW.is_contiguous() &&
                   dW.numel() == N * taps * C && (reinterpret_cast<uintptr_t>(dW.data_ptr()) % 16) == 0,
               "dW must be a contiguous aligned [N, taps*C] float32 tensor");
-  const int other = taps == 1 ? (int)(((C + 127) / 128) * ((N + 127) / 128)) : (int)(3 * ((C + 127) / 128));
-  p.rows_per_wg = ddl::wgrad_rows_per_wg((int)M, other, (int)min_rows, taps == 1 ? 512 : 768);
+  int other;
+  if (taps == 1) {
+    ddl::wgrad1x1_tiling((int)M, (int)C, (int)N, (int)force_sub, p.sub, p.ctiles);
+    TORCH_CHECK(p.sub >= 1 && p.sub <= 4 && p.sub != 2 && (int64_t)p.ctiles * p.sub * 32 >= C, "wgrad tiling does not cover C");
+    other = (int)(p.ctiles * ((N + 127) / 128));
+  } else {
+    other = (int)(3 * ((C + 127) / 128));
+  }
+  // resident workgroup slots: 1x1 with 128-column tiles 2 per CU (64 KB LDS), 32-column tiles 3-4 per CU (40 KB, registers)
+  static const int target1 = [] { const char* e = getenv("DDL_WGRAD_TARGET1"); return e ? atoi(e) : 512; }();
+  p.rows_per_wg = ddl::wgrad_rows_per_wg((int)M, other, (int)min_rows, taps == 1 ? (p.sub == 1 ? target1 : 512) : 768);
   p.S = (int)((M + p.rows_per_wg - 1) / p.rows_per_wg);
   auto slabs = at::empty({p.S, N, taps * C}, d0.options());
   p.slabs = slabs.data_ptr<float>();
-  ddl::launch_wgrad(p, dW.data_ptr<float>(), cur_stream());
+  ddl::launch_wgrad(p, cur_stream());
+  const int64_t total4 = N * taps * C / 4;
+  if (queue != nullptr) {
+    queue->push(slabs, dW, p.S, total4);
+  } else {
+    ddl::SlabReduceParams r{};
+    r.n = 1;
+    r.e[0].slabs = p.slabs; r.e[0].dW = dW.data_ptr<float>(); r.e[0].S = p.S; r.e[0].total4 = (long)total4;
+    ddl::launch_slab_reduce_multi(r, cur_stream());
+  }
 }
 
 void bn_prep(const OptT& partials, int64_t new0, int64_t n_new, double count, at::Tensor chan_mean,
@@ -383,7 +432,12 @@ void register_conv_ops(pybind11::module_& m) {
         pybind11::arg("a0"), pybind11::arg("as0"), pybind11::arg("as2"), pybind11::arg("a_relu"), pybind11::arg("M"),
         pybind11::arg("H"), pybind11::arg("W"), pybind11::arg("taps"), pybind11::arg("dW"), pybind11::arg("min_rows"),
         pybind11::arg("k_acc") = c10::nullopt, pybind11::arg("k_mean") = c10::nullopt,
-        pybind11::arg("k_rstd") = c10::nullopt, pybind11::arg("k_scale") = c10::nullopt, pybind11::arg("k_count") = 0.0);
+        pybind11::arg("k_rstd") = c10::nullopt, pybind11::arg("k_scale") = c10::nullopt, pybind11::arg("k_count") = 0.0,
+        pybind11::arg("queue") = nullptr, pybind11::arg("force_sub") = 0);
+  pybind11::class_<SlabQueue>(m, "SlabQueue")
+      .def(pybind11::init<>())
+      .def("flush", &SlabQueue::flush)
+      .def("__len__", &SlabQueue::size);
   m.def("bn_prep", &bn_prep, "finalize channel statistics, derive BN scale/shift, update running stats");
   m.def("bn_bwd_prep", &bn_bwd_prep, "BN backward per-channel coefficients, dgamma/dbeta");
   m.def("rows_op", &rows_op, "pixel glue ops (copy+stats, pool fwd/bwd, gap bwd, deferred-term apply)");

@@ -125,6 +125,22 @@ struct WgradParams {
   int rows_per_wg;    // multiple of 32
   float* slabs;       // [S][N][taps*C]  partial sums, one slab per M-chunk
   int S;
+  int sub;            // 1x1: 32-column sub-tiles per workgroup tile (1..4) and the number of channel tiles
+  int ctiles;
+};
+
+// deferred slab reductions: dW += sum over S slabs, many weight gradients in one launch (conv_wgrad.hip)
+constexpr int kMaxSlabEntries = 64;
+struct SlabEntry {
+  const float* slabs;
+  float* dW;
+  long total4;        // float4 elements of dW
+  int S;
+  int block0;         // first workgroup of this entry (filled by the launcher)
+};
+struct SlabReduceParams {
+  SlabEntry e[kMaxSlabEntries];
+  int n;
 };
 
 }  // namespace ddl

@@ -16,6 +16,8 @@
 // MFMA mapping (v_mfma_f32_32x32x2_f32): D[i = n][j = c] += sum_m dO[m][n] * A[m][c]; both LDS
 // tiles keep the pixel axis as rows, so lane (i, h) reads row 2s+h, column i: 32 consecutive
 // floats per half-wave - conflict-free ds_read_b32.
+#include <cstdlib>
+
 #include "conv_params.h"
 #include "ddl_kernels.h"
 #include "device_utils.h"
@@ -105,30 +107,40 @@ __device__ __forceinline__ bool xcd_group(int id, int T, int S, int& t, int& chu
 }
 
 // ---------------------------------------------------------------------------------------------
-// 1x1: output tile 128 (n) x 128 (c) per workgroup, 2x2 waves of 64x64.
-// grid = (c tiles, n tiles, S)
+// 1x1: output tile 128 (n) x 32*SUB (c) per workgroup.  The four waves split the n axis (32 rows each) and every
+// wave walks all SUB 32-column sub-tiles of the tile: whatever C is, the four waves do the same work (the 2x2
+// wave layout of round 1 left two waves idle whenever the last channel tile was at most half full - C grows by 32
+// per dense layer, so in block 1 that was the common case).  The host picks SUB and the number of channel tiles
+// so that the tiles are balanced (C = 160: 96 + 64, not 128 + 32) and, for the small feature maps, so that the
+// channel axis - not the pixel axis - supplies the workgroups: the slab traffic is S x N x C x 4 bytes, and with
+// 32-column tiles a 14x14 layer needs 4-5x fewer pixel chunks S for the same number of workgroups.
+// grid = (c tiles x n tiles x S), XCD-grouped.
 // ---------------------------------------------------------------------------------------------
-template <bool DTWO>
-__global__ void __launch_bounds__(256) wgrad1x1_kernel(const WgradParams p) {
+template <int SUB, bool DTWO, int PF>
+__global__ void __launch_bounds__(256, 2) wgrad1x1_kernel(const WgradParams p) {
+  constexpr int TC = 32 * SUB;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ds = smem;                     // [2][RK][128]
-  float* As = smem + 2 * RK * 128;      // [2][RK][128]
+  float* As = smem + 2 * RK * 128;      // [2][RK][TC]
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar wave index
-  const int wm = wid >> 1, wn = wid & 1;
   const int li = lane & 31, lh = lane >> 5;
-  const int ctiles = (p.C + 127) / 128, ntiles = (p.N + 127) / 128;
+  const int ctiles = p.ctiles, ntiles = (p.N + 127) / 128;
   int t_idx, chunk;
   if (!xcd_group(blockIdx.x, ctiles * ntiles, p.S, t_idx, chunk)) return;     // grid padded to 8 chunks
-  const int c0 = (t_idx % ctiles) * 128, n0 = (t_idx / ctiles) * 128;
+  const int c0 = (t_idx % ctiles) * TC, n0 = (t_idx / ctiles) * 128;
   const int mb = chunk * p.rows_per_wg;
   int me = mb + p.rows_per_wg;
   if (me > p.M) me = p.M;
   const int steps = (me - mb + RK - 1) / RK;
   const SrcDesc dd = src_desc(p.d), da = src_desc(p.a);
 
-  const int q = 4 * (tid & 31);          // this thread's channel quad in both tiles (f & 31 == tid & 31)
+  const int q = 4 * (tid & 31);          // dO tile: this thread's channel quad, rows (tid >> 5) + 8 i
+  const int ar = tid >> 3;               // activation tile: this thread's row, channel quads 4 (tid & 7) + 32 j
+  const int aq = 4 * (tid & 7);
   ColAffine kd = col_affine(p.d, n0 + q, n0 + q < p.N);
-  const ColAffine ka = col_affine(p.a, c0 + q, c0 + q < p.C);
+  ColAffine ka[SUB];
+#pragma unroll
+  for (int j = 0; j < SUB; ++j) ka[j] = col_affine(p.a, c0 + 32 * j + aq, c0 + 32 * j + aq < p.C);
   if (p.fk.acc != nullptr) {
     // fused BN backward: dO = k0*g + k1*h + k2 with the k's derived here from the (sum g, sum g*h)
     // accumulators the producing data-gradient kernel filled (no bn_bwd_prep launch in between)
@@ -142,82 +154,107 @@ __global__ void __launch_bounds__(256) wgrad1x1_kernel(const WgradParams p) {
     kd.s0 = ld4(kt + q); kd.s1 = ld4(kt + 128 + q); kd.s2 = ld4(kt + 256 + q);
     __syncthreads();
   }
-  RawPix d_raw[4], a_raw[4];
-  auto load_step = [&](int st) {
+  struct Raw { RawPix d[4], a[SUB]; };
+  auto load_step = [&](int st, Raw& R) {
     const int mrow = mb + st * RK;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int f = tid + i * 256;
-      const int m = mrow + (f >> 5);
-      d_raw[i] = pix_fetch<DTWO>(dd, m, n0 + q, m < me && n0 + q < p.N);
-      a_raw[i] = pix_fetch<false>(da, m, c0 + q, m < me && c0 + q < p.C);
+      const int m = mrow + (tid >> 5) + 8 * i;
+      R.d[i] = pix_fetch<DTWO>(dd, m, n0 + q, m < me && n0 + q < p.N);
     }
-  };
-  auto store_step = [&](int buf) {
+    const int m = mrow + ar;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f = tid + i * 256;
-      *reinterpret_cast<f32x4*>(Ds + buf * RK * 128 + (f >> 5) * 128 + q) = pix_apply<DTWO>(d_raw[i], kd);
-      *reinterpret_cast<f32x4*>(As + buf * RK * 128 + (f >> 5) * 128 + q) = pix_apply<false>(a_raw[i], ka);
+    for (int j = 0; j < SUB; ++j)
+      R.a[j] = pix_fetch<false>(da, m, c0 + 32 * j + aq, m < me && c0 + 32 * j + aq < p.C);
+  };
+  auto store_step = [&](int buf, const Raw& R) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<f32x4*>(Ds + buf * RK * 128 + ((tid >> 5) + 8 * i) * 128 + q) = pix_apply<DTWO>(R.d[i], kd);
+#pragma unroll
+    for (int j = 0; j < SUB; ++j)
+      *reinterpret_cast<f32x4*>(As + buf * RK * TC + ar * TC + 32 * j + aq) = pix_apply<false>(R.a[j], ka[j]);
+  };
+
+  f32x16 acc[SUB];
+#pragma unroll
+  for (int j = 0; j < SUB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  // sub-tiles beyond C (the last channel tile of an unbalanced split): wave-uniform skip
+  bool live[SUB];
+#pragma unroll
+  for (int j = 0; j < SUB; ++j) live[j] = c0 + 32 * j < p.C;
+
+  auto compute = [&](int buf) {
+    const float* Db = Ds + buf * RK * 128 + wid * 32 + li;
+    const float* Ab = As + buf * RK * TC + li;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {     // operands of 8 k-pairs at a time: the MFMAs then issue back to back
+      float d[RK / 4], av[RK / 4][SUB];
+#pragma unroll
+      for (int s = 0; s < RK / 4; ++s) {
+        const int r = 2 * (half * (RK / 4) + s) + lh;
+        d[s] = Db[r * 128];
+#pragma unroll
+        for (int j = 0; j < SUB; ++j) av[s][j] = Ab[r * TC + 32 * j];
+      }
+#pragma unroll
+      for (int s = 0; s < RK / 4; ++s)
+#pragma unroll
+        for (int j = 0; j < SUB; ++j)
+          if (live[j]) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[s], av[s][j], acc[j], 0, 0, 0);
     }
   };
 
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  if (steps > 0) {
-    load_step(0);
-    store_step(0);
-  }
-  __syncthreads();
-  for (int st = 0; st < steps; ++st) {
-    const int buf = st & 1;
-    if (st + 1 < steps) load_step(st + 1);
-    const float* Db = Ds + buf * RK * 128 + wm * 64 + li;
-    const float* Ab = As + buf * RK * 128 + wn * 64 + li;
-    // all 16 k-pairs' operands are read up front (64 VGPRs): the MFMAs then issue back to back
-    float d0[RK / 2], d1[RK / 2], a0[RK / 2], a1[RK / 2];
-#pragma unroll
-    for (int s = 0; s < RK / 2; ++s) {
-      const int r = 2 * s + lh;
-      d0[s] = Db[r * 128]; d1[s] = Db[r * 128 + 32];
-      a0[s] = Ab[r * 128]; a1[s] = Ab[r * 128 + 32];
+  if (PF == 1) {
+    Raw R;
+    if (steps > 0) {
+      load_step(0, R);
+      store_step(0, R);
     }
-    // C grows by 32 per dense layer: the last channel tile is often mostly empty - skip its
-    // 32-column sub-tiles that lie beyond C (wave-uniform)
-    const bool c_lo = c0 + wn * 64 < p.C, c_hi = c0 + wn * 64 + 32 < p.C;
-#pragma unroll
-    for (int s = 0; s < RK / 2; ++s) {
-      if (c_lo) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d0[s], a0[s], acc[0][0], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1[s], a0[s], acc[1][0], 0, 0, 0);
-      }
-      if (c_hi) {
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d0[s], a1[s], acc[0][1], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1[s], a1[s], acc[1][1], 0, 0, 0);
-      }
-    }
-    if (st + 1 < steps) store_step(buf ^ 1);
     __syncthreads();
+#pragma unroll 1
+    for (int st = 0; st < steps; ++st) {
+      const int buf = st & 1;
+      if (st + 1 < steps) load_step(st + 1, R);
+      compute(buf);
+      if (st + 1 < steps) store_step(buf ^ 1, R);
+      __syncthreads();
+    }
+  } else {
+    // prefetch distance 2: step st in LDS, st+1 in registers, st+2 being loaded.  A 32-column tile has only
+    // 16 MFMAs (1024 cycles) per wave and step - far less than one trip to HBM / L2 under load, so with a
+    // single step in flight the loop runs at memory latency; two steps give every load two compute phases.
+    Raw R0, R1;
+    if (steps > 0) load_step(0, R0);
+    if (steps > 1) load_step(1, R1);
+    if (steps > 0) store_step(0, R0);
+    __syncthreads();
+#pragma unroll 1
+    for (int st = 0; st < steps; st += 2) {
+      if (st + 2 < steps) load_step(st + 2, R0);
+      compute(0);
+      if (st + 1 < steps) store_step(1, R1);
+      __syncthreads();
+      if (st + 1 >= steps) break;
+      if (st + 3 < steps) load_step(st + 3, R1);
+      compute(1);
+      if (st + 2 < steps) store_step(0, R0);
+      __syncthreads();
+    }
   }
-  // slab write: slabs[z][n][c]
+  // slab write: slabs[chunk][n][c]
   float* slab = p.slabs + (long)chunk * p.N * p.C;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < SUB; ++j) {
+    const int c = c0 + 32 * j + li;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = c0 + wn * 64 + j * 32 + li;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (n < p.N && c < p.C) slab[(long)n * p.C + c] = acc[i][j][r];
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (n < p.N && c < p.C) slab[(long)n * p.C + c] = acc[j][r];
     }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -335,14 +372,20 @@ __global__ void __launch_bounds__(256) wgrad3x3_kernel(const WgradParams p) {
   }
 }
 
-// dW[e] += sum_s slabs[s][e]: 16 float4 columns x 16 S-slices per workgroup, independent loads
-// 4 deep, fixed combine order => deterministic.
-__global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, int S,
-                                                          long total4, float* __restrict__ dW) {
+// dW[e] += sum_s slabs[s][e] for a whole LIST of weight gradients in one launch: the dense-block backward queues
+// (slabs, S, dW) of every layer and reduces them once, at the end of the block (119 slab_reduce launches per step
+// in round 1 -> 4 + the transitions).  Per workgroup: 16 float4 columns x 16 S-slices of one entry, independent
+// loads 4 deep, fixed combine order => deterministic.
+__global__ void __launch_bounds__(256) slab_reduce_multi_kernel(const SlabReduceParams p) {
   __shared__ f32x4 red[16][16];
+  int e = 0;
+  while (e + 1 < p.n && (int)blockIdx.x >= p.e[e + 1].block0) ++e;           // scalar walk over <= 64 entries
+  const SlabEntry en = p.e[e];
+  const int S = en.S;
+  const long total4 = en.total4;
   const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const long i = blockIdx.x * 16L + col;
-  const f32x4* src = reinterpret_cast<const f32x4*>(slabs);
+  const long i = ((long)blockIdx.x - en.block0) * 16L + col;
+  const f32x4* src = reinterpret_cast<const f32x4*>(en.slabs);
   f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
   if (i < total4) {
     int k = sl;
@@ -357,10 +400,10 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
   red[sl][col] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (sl == 0 && i < total4) {
-    f32x4 s = reinterpret_cast<f32x4*>(dW)[i];
+    f32x4 s = reinterpret_cast<f32x4*>(en.dW)[i];
 #pragma unroll
     for (int k = 0; k < 16; ++k) s += red[k][col];
-    reinterpret_cast<f32x4*>(dW)[i] = s;
+    reinterpret_cast<f32x4*>(en.dW)[i] = s;
   }
 }
 
@@ -378,34 +421,74 @@ int wgrad_rows_per_wg(int M, int other_grid, int min_rows, int target_wgs) {
   return (int)rows;
 }
 
-void launch_wgrad(const WgradParams& p, float* dW, hipStream_t s) {
+// 1x1 tiling: SUB 32-column sub-tiles per workgroup tile and the number of channel tiles.
+//  * the widest tile (fewest re-reads of dO, least staging per MFMA) whose pixel chunks stay >= `min_steps`
+//    steps of 32 rows with one round of resident workgroups; the small feature maps fall through to SUB = 1,
+//    where the channel axis supplies the workgroups and the slab volume S x N x C x 4 B shrinks with S;
+//  * tiles are balanced: ctiles = ceil(nsub / SUB), then SUB = ceil(nsub / ctiles).
+void wgrad1x1_tiling(int M, int C, int N, int force_sub, int& sub, int& ctiles) {
+  static const int min_steps = [] { const char* e = getenv("DDL_WGRAD_MIN_STEPS"); return e ? atoi(e) : 2; }();
+  const int nsub = (C + 31) / 32, ntiles = (N + 127) / 128;
+  auto balanced = [&](int want, int& sb, int& ct) {
+    ct = (nsub + want - 1) / want;
+    sb = (nsub + ct - 1) / ct;
+    if (sb == 2) { sb = 1; ct = nsub; }     // no SUB = 2 instantiation: hipcc's register allocation of that one form
+  };                                         // needs > 256 VGPRs (spills); 32-column tiles take its place
+  if (force_sub >= 1 && force_sub <= 4) {
+    balanced(force_sub, sub, ctiles);
+    return;
+  }
+  for (int want = 4; want >= 1; --want) {
+    balanced(want, sub, ctiles);
+    const long chunks = (512 + (long)ctiles * ntiles - 1) / ((long)ctiles * ntiles);
+    if (want == 1 || (long)M >= chunks * 32L * min_steps) return;
+  }
+}
+
+void launch_wgrad(const WgradParams& p, hipStream_t s) {
   static bool attr = false;
-  const size_t lds1 = (size_t)4 * RK * 128 * sizeof(float);
   const size_t lds3 = (size_t)(2 * RK * 32 + 2 * (RK + 2) * 128 + 2 * RK) * sizeof(float);
+  auto lds1 = [](int sub) { return (size_t)2 * RK * (128 + 32 * sub) * sizeof(float); };
   if (!attr) {
-    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x1_kernel<false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x1_kernel<true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+#define DDL_SET_LDS(K, BYTES) DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
+    DDL_SET_LDS((wgrad1x1_kernel<1, false, 2>), lds1(1)); DDL_SET_LDS((wgrad1x1_kernel<1, true, 2>), lds1(1));
+    DDL_SET_LDS((wgrad1x1_kernel<1, false, 1>), lds1(1)); DDL_SET_LDS((wgrad1x1_kernel<1, true, 1>), lds1(1));
+    DDL_SET_LDS((wgrad1x1_kernel<3, false, 1>), lds1(3)); DDL_SET_LDS((wgrad1x1_kernel<3, true, 1>), lds1(3));
+    DDL_SET_LDS((wgrad1x1_kernel<4, false, 1>), lds1(4)); DDL_SET_LDS((wgrad1x1_kernel<4, true, 1>), lds1(4));
+    DDL_SET_LDS((wgrad3x3_kernel<false>), lds3); DDL_SET_LDS((wgrad3x3_kernel<true>), lds3);
+#undef DDL_SET_LDS
     attr = true;
   }
   const bool two = p.d.X1 != nullptr;
   if (p.taps == 1) {
-    dim3 grid((unsigned)(((p.C + 127) / 128) * ((p.N + 127) / 128) * 8 * ((p.S + 7) / 8)));
-    if (two) hipLaunchKernelGGL(wgrad1x1_kernel<true>, grid, dim3(256), lds1, s, p);
-    else hipLaunchKernelGGL(wgrad1x1_kernel<false>, grid, dim3(256), lds1, s, p);
+    dim3 grid((unsigned)(p.ctiles * ((p.N + 127) / 128) * 8 * ((p.S + 7) / 8)));
+#define DDL_W1(SUBV, PFV)                                                                                    \
+    if (two) hipLaunchKernelGGL((wgrad1x1_kernel<SUBV, true, PFV>), grid, dim3(256), lds1(SUBV), s, p);        \
+    else hipLaunchKernelGGL((wgrad1x1_kernel<SUBV, false, PFV>), grid, dim3(256), lds1(SUBV), s, p)
+    static const bool pf2 = [] { const char* e = getenv("DDL_WGRAD_PF2"); return !(e && e[0] == '0'); }();
+    switch (p.sub) {
+      case 1: if (pf2) { DDL_W1(1, 2); } else { DDL_W1(1, 1); } break;
+      case 3: DDL_W1(3, 1); break;
+      default: DDL_W1(4, 1); break;
+    }
+#undef DDL_W1
   } else {
     dim3 grid((unsigned)(3 * ((p.C + 127) / 128) * 8 * ((p.S + 7) / 8)));
     if (two) hipLaunchKernelGGL(wgrad3x3_kernel<true>, grid, dim3(256), lds3, s, p);
     else hipLaunchKernelGGL(wgrad3x3_kernel<false>, grid, dim3(256), lds3, s, p);
   }
-  const long total4 = (long)p.N * p.taps * p.C / 4;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total4 + 15) / 16)), dim3(256), 0, s,
-                     p.slabs, p.S, total4, dW);
+}
+
+// one launch for up to kMaxSlabEntries queued (slabs, S, total4, dW) reductions; block0 is filled here
+void launch_slab_reduce_multi(SlabReduceParams& p, hipStream_t s) {
+  if (p.n <= 0) return;
+  long blocks = 0;
+  for (int i = 0; i < p.n; ++i) {
+    p.e[i].block0 = (int)blocks;
+    blocks += (p.e[i].total4 + 15) / 16;
+  }
+  hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
 }
 
 }  // namespace ddl

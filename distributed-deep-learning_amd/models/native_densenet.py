@@ -162,6 +162,10 @@ class _BlockFn(torch.autograd.Function):
         fused = unit.stage.fused_bwd
         if fused:     # (sum g2, sum g2*h) accumulators: BN2-backward coefficients are derived by their consumers
             acc_g = torch.zeros(L, ext.STAT_REPLICAS, 2, MID, dtype=torch.int64, device=buf.device)
+        # every layer's weight-gradient kernels leave partial slabs; ONE launch at the end of the block adds them
+        # into the gradient arena (2 slab_reduce launches per layer otherwise: 116 of the step's 660 graph nodes)
+        defer = unit.stage.defer_slab_reduce          # "block" | "layer" | "" (reduce behind every kernel)
+        wq = dict(queue=ext.SlabQueue()) if defer else {}
         for l in range(L - 1, -1, -1):
             lay = unit.layers[l]
             C = C0 + GROWTH * l
@@ -183,10 +187,10 @@ class _BlockFn(torch.autograd.Function):
                 side.wait_event(ev0)
                 with torch.cuda.stream(side):
                     ext.conv_wgrad(dy, xs, ones[:GROWTH], nq[sl], np_[sl], h[l], sc2, sh2, True, M, H, W, 9,
-                                   lay.gw2, min_rows)
+                                   lay.gw2, min_rows, **wq)
             else:
                 ext.conv_wgrad(dy, xs, ones[:GROWTH], nq[sl], np_[sl], h[l], sc2, sh2, True, M, H, W, 9,
-                               lay.gw2, min_rows)
+                               lay.gw2, min_rows, **wq)
             if fused:
                 kd = (None, None, None)
                 kf = dict(k_acc=acc_g[l], k_mean=bn2[l, 0], k_rstd=bn2[l, 2], k_scale=sc2, k_count=float(M))
@@ -202,17 +206,27 @@ class _BlockFn(torch.autograd.Function):
                 side.wait_event(ev1)
                 with torch.cuda.stream(side):
                     ext.conv_wgrad(g2[par], h[l], *kd, buf2d[:, :C], sc1[l], sh1[l],
-                                   True, M, H, W, 1, lay.gw1, min_rows, **kf)
+                                   True, M, H, W, 1, lay.gw1, min_rows, **kf, **wq)
+                    if defer == "layer":
+                        wq["queue"].flush()       # the layer's 3x3 + 1x1 slabs in one launch, still cache-resident
                     done[par] = torch.cuda.Event()
                     done[par].record(side)
             else:
                 ext.conv_wgrad(g2[par], h[l], *kd, buf2d[:, :C], sc1[l], sh1[l],
-                               True, M, H, W, 1, lay.gw1, min_rows, **kf)
+                               True, M, H, W, 1, lay.gw1, min_rows, **kf, **wq)
+                if defer == "layer":
+                    wq["queue"].flush()
             # 1x1 data gradient: dh = k0*g2 + k1*h + k2 on the fly; epilogue: mask, dBuf += sc1*g1, sums
             st1 = ext.conv_gemm(g2[par], h[l], *kd, False, M, H, W, 1, False,
                                 lay.w1, True, d2d[:, :C], True, True, buf2d[:, :C], sc1[l], sh1[l], 2, 0, bf,
                                 **kf, **kg)
             ext.bn_bwd_prep(st1, float(M), stats[0], stats[2], sc1[l], lay.gg1, lay.gb1, None, nq, np_, C, 1)
+        if wq:
+            if side is not None:
+                with torch.cuda.stream(side):
+                    wq["queue"].flush()
+            else:
+                wq["queue"].flush()
         if side is not None:
             unit.stage.join(main, side)
         dx = torch.empty(B, H, W, C0, **f32)
@@ -476,6 +490,12 @@ class NativeDenseNetStage(nn.Module):
         self.fused_bwd = os.environ.get("DDL_FUSED_BWD", "0") == "1"
         # g2 / k buffers of the dense-block backward: how many layers the weight-gradient stream may lag
         self.g2_bufs = max(1, int(os.environ.get("DDL_G2_BUFS", "2")))
+        # slab reductions of the weight gradients (csrc/conv_bindings.cpp SlabQueue): "layer" = one launch per dense
+        # layer for its 3x3 + 1x1 slabs (58 fewer graph nodes than one per kernel); "block" = one per dense block
+        # (116 fewer nodes, but measured 0.4 ms/step SLOWER at batch 30: the slabs of 24 layers no longer fit the
+        # 256 MB Infinity Cache and come back from HBM); "0" = behind every kernel
+        d = os.environ.get("DDL_DEFER_SLABS", "layer")
+        self.defer_slab_reduce = d if d in ("layer", "block") else ""
         ops.require_ext()
         device = torch.device(device)
         if device.type != "cuda":
