@@ -1,0 +1,13 @@
+#!/bin/bash
+set -o pipefail
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r2k
+mkdir -p $O
+timeout -k 10 600 python -u -m pytest tests/test_gpu_native.py tests/test_gpu_kernels_real.py -m gpu -q -x --timeout 300 --timeout-method thread -k "dense_block or full_model or block_transition or head or trajectory or loss_curve or odd_batches" > $O/pytest.log 2>&1
+rc=$?; tail -8 $O/pytest.log
+[ $rc -ne 0 ] && exit $rc
+for cfg in "1 auto" "0 auto" "1 4" "1 2"; do
+  set -- $cfg
+  DDL_TAIL_PREP=$1 DDL_WGRAD_GROUP=$2 timeout -k 10 200 python bench.py > $O/bench_t$1_g$2.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
+  echo "tail=$1 group=$2: $(grep -o '"ms_per_step": [0-9.]*' $O/bench_t$1_g$2.json | head -1)"
+done

@@ -5,6 +5,8 @@
 #include "torch_hip.h"
 #include "ddl_kernels.h"
 
+#include <cstdlib>
+
 namespace {
 
 using OptT = c10::optional<at::Tensor>;
@@ -92,7 +94,10 @@ at::Tensor conv_gemm(const at::Tensor& x0, const OptT& x1, const OptT& s0, const
                      const at::Tensor& weight, bool b_kmajor, at::Tensor out, bool ep_mask, bool ep_accum,
                      const OptT& aux, const OptT& e0, const OptT& e1, int64_t stats_mode, int64_t force_bm, bool bf16,
                      const OptT& acc_out, const OptT& k_acc, const OptT& k_mean, const OptT& k_rstd,
-                     const OptT& k_scale, const OptT& k_dgamma, const OptT& k_dbeta, double k_count) {
+                     const OptT& k_scale, const OptT& k_dgamma, const OptT& k_dbeta, double k_count,
+                     const OptT& tail_counters, int64_t tail_mode, double tail_count, const OptT& tail_mean,
+                     const OptT& tail_rstd, const OptT& tail_scale, const OptT& tail_dgamma, const OptT& tail_dbeta,
+                     const OptT& tail_k0, const OptT& tail_k1, const OptT& tail_k2) {
   ddl::DeviceGuard guard(x0.device());
   const int64_t C = x0.size(1), N = out.size(1);
   TORCH_CHECK(taps == 1 || taps == 9, "taps must be 1 or 9");
@@ -145,7 +150,7 @@ at::Tensor conv_gemm(const at::Tensor& x0, const OptT& x1, const OptT& s0, const
   if (p.kind == 0 && p.a.s0 != nullptr) { TORCH_CHECK(C <= ddl::kMaxAffineC, "conv_gemm: BN prologue for <= 1024 channels"); }
   at::Tensor stats;
   if (acc_out.has_value()) {            // statistics into fixed-point accumulators instead of a per-tile table
-    TORCH_CHECK(stats_mode != 0 && (p.kind == 0 || p.kind == 2), "acc_out: forward / 3x3 data-gradient statistics only");
+    TORCH_CHECK(stats_mode != 0 && (p.kind == 0 || p.kind == 2 || p.kind == 3), "acc_out: forward / data-gradient statistics only");
     check_acc(*acc_out, N, "acc_out");
     p.bn.acc_out = reinterpret_cast<long long*>(acc_out->data_ptr<int64_t>());
     p.bn.acc_out_ld = (int)acc_out->stride(1);
@@ -153,6 +158,27 @@ at::Tensor conv_gemm(const at::Tensor& x0, const OptT& x1, const OptT& s0, const
     const int G = ddl::conv_gemm_grid_x(p, (int)force_bm);
     stats = at::empty({G, 2, N}, x0.options());
     p.stats_out = stats.data_ptr<float>();
+  }
+  if (tail_counters.has_value()) {      // BN-backward bookkeeping in the kernel's tail (TailPrep, conv_params.h)
+    TORCH_CHECK((p.kind == 2 || p.kind == 3) && acc_out.has_value() && stats_mode == 2,
+                "tail prep: data-gradient kinds with accumulator statistics only");
+    TORCH_CHECK(tail_mode == 0 || tail_mode == 1, "tail_mode");
+    const at::Tensor& ct = *tail_counters;
+    TORCH_CHECK(ct.is_cuda() && ct.scalar_type() == at::kInt && ct.is_contiguous() && ct.numel() >= (N + 31) / 32,
+                "tail_counters: contiguous int32 tensor with one ticket per 32 output columns");
+    TORCH_CHECK(tail_count > 0 && tail_mean.has_value() && tail_rstd.has_value() && tail_scale.has_value() &&
+                    tail_dgamma.has_value() && tail_dbeta.has_value() && tail_k1.has_value() && tail_k2.has_value(),
+                "tail prep: count, mean, rstd, scale, dgamma, dbeta, k1, k2");
+    p.tail.counters = reinterpret_cast<unsigned*>(ct.data_ptr<int>());
+    p.tail.mode = (int)tail_mode;
+    static const int tail_fence = [] { const char* e = getenv("DDL_TAIL_FENCE"); return (e && e[0] == '1') ? 1 : 0; }();
+    p.tail.fence = tail_fence;
+    p.tail.inv_count = 1.0 / tail_count;
+    p.tail.mean = fvec(*tail_mean, N, "tail_mean"); p.tail.rstd = fvec(*tail_rstd, N, "tail_rstd");
+    p.tail.scale = fvec(*tail_scale, N, "tail_scale");
+    p.tail.dgamma = fvec(*tail_dgamma, N, "tail_dgamma"); p.tail.dbeta = fvec(*tail_dbeta, N, "tail_dbeta");
+    p.tail.k1 = fvec(*tail_k1, N, "tail_k1"); p.tail.k2 = fvec(*tail_k2, N, "tail_k2");
+    if (tail_mode == 0) { TORCH_CHECK(tail_k0.has_value(), "tail mode 0 needs k0"); p.tail.k0 = fvec(*tail_k0, N, "tail_k0"); }
   }
   ddl::launch_conv_gemm(p, (int)force_bm, cur_stream());
   return stats;
@@ -316,6 +342,67 @@ void conv_wgrad(const at::Tensor& d0, const OptT& d1, const OptT& ds0, const Opt
   }
 }
 
+// Weight gradients of up to 24 dense layers in ONE launch (conv_wgrad.hip: wgrad_group_kernel).  Entry i:
+//   dW[i][N, taps*C_i] += (ds0[i]*d0[i] + ds1[i]*d1[i] + ds2[i])^T  (*)  relu(as0[i]*a0[i] + as2[i])
+// All entries share M, N, H, W, taps and the row strides of their operands.  The slab reduction goes to `queue`.
+void conv_wgrad_group(int64_t taps, std::vector<at::Tensor> d0, std::vector<at::Tensor> d1, std::vector<at::Tensor> ds0,
+                      std::vector<at::Tensor> ds1, std::vector<at::Tensor> ds2, std::vector<at::Tensor> a0,
+                      std::vector<at::Tensor> as0, std::vector<at::Tensor> as2, std::vector<at::Tensor> dW, int64_t M,
+                      int64_t H, int64_t W, SlabQueue* queue) {
+  const size_t n = d0.size();
+  TORCH_CHECK(n >= 1 && n <= (size_t)ddl::kMaxWgradGroup, "conv_wgrad_group: 1..", ddl::kMaxWgradGroup, " layers");
+  TORCH_CHECK(d1.size() == n && ds0.size() == n && ds1.size() == n && ds2.size() == n && a0.size() == n &&
+                  as0.size() == n && as2.size() == n && dW.size() == n, "conv_wgrad_group: list lengths differ");
+  TORCH_CHECK(queue != nullptr, "conv_wgrad_group: a SlabQueue is required");
+  TORCH_CHECK(taps == 1 || taps == 9, "taps must be 1 or 9");
+  TORCH_CHECK(M > 0 && M < (1LL << 31), "bad M");
+  ddl::DeviceGuard guard(d0[0].device());
+  const int64_t N = d0[0].size(1);
+  if (taps == 9) {
+    TORCH_CHECK(N <= 32 && N % 4 == 0, "3x3 wgrad: N <= 32 output channels");
+    TORCH_CHECK(H > 0 && W > 0 && M % (H * W) == 0, "M must be a whole number of HxW images");
+  }
+  ddl::WgradGroupParams g{};
+  g.n = (int)n; g.M = (int)M; g.N = (int)N; g.H = (int)H; g.W = (int)W; g.taps = (int)taps; g.a_relu = 1;
+  int64_t tiles = 0, slab_elems = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const int64_t C = a0[i].size(1);
+    TORCH_CHECK(d0[i].size(1) == N && d1[i].size(1) == N, "conv_wgrad_group: dO channel counts differ");
+    const ddl::RowSrc d = make_src(d0[i], d1[i], ds0[i], ds1[i], ds2[i], false, M, N, "wgrad group dO");
+    const ddl::RowSrc a = make_src(a0[i], c10::nullopt, as0[i], c10::nullopt, as2[i], true, M, C, "wgrad group activation");
+    if (i == 0) { g.ld_d0 = d.ld0; g.ld_d1 = d.ld1; g.ld_a0 = a.ld0; }
+    TORCH_CHECK(d.ld0 == g.ld_d0 && d.ld1 == g.ld_d1 && a.ld0 == g.ld_a0, "conv_wgrad_group: entries must share row strides");
+    TORCH_CHECK(taps == 1 || C == 128, "3x3 wgrad group: 128 input channels");
+    TORCH_CHECK(dW[i].is_cuda() && dW[i].scalar_type() == at::kFloat && dW[i].is_contiguous() &&
+                    dW[i].numel() == N * taps * C && (reinterpret_cast<uintptr_t>(dW[i].data_ptr()) % 16) == 0,
+                "dW must be a contiguous aligned [N, taps*C] float32 tensor");
+    ddl::WgradGroupEntry& e = g.e[i];
+    e.d0 = d.X0; e.d1 = d.X1; e.ds0 = d.s0; e.ds1 = d.s1; e.ds2 = d.s2;
+    e.a0 = a.X0; e.as0 = a.s0; e.as2 = a.s2;
+    e.C = (int)C;
+    e.ctiles = (int)((C + 127) / 128);
+    tiles += taps == 1 ? e.ctiles * ((N + 127) / 128) : 3 * ((C + 127) / 128);
+    slab_elems += N * taps * C;
+  }
+  // pixel chunking: about `target` workgroups in all (two rounds of the resident slots), every chunk >= 4 steps
+  static const int target = [] { const char* e = getenv("DDL_WGRAD_GROUP_WGS"); return e ? atoi(e) : 768; }();
+  int64_t chunks = (target + tiles - 1) / tiles;
+  int64_t rows = (M + chunks - 1) / chunks;
+  if (rows < 128) rows = 128;
+  rows = (rows + 31) / 32 * 32;
+  g.rows_per_wg = (int)rows;
+  g.S = (int)((M + rows - 1) / rows);
+  auto slabs = at::empty({(int64_t)g.S * slab_elems}, d0[0].options());
+  int64_t off = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const int64_t per = N * taps * a0[i].size(1);
+    g.e[i].slabs = slabs.data_ptr<float>() + off;
+    queue->push(slabs.narrow(0, off, (int64_t)g.S * per), dW[i], g.S, per / 4);
+    off += (int64_t)g.S * per;
+  }
+  ddl::launch_wgrad_group(g, cur_stream());
+}
+
 void bn_prep(const OptT& partials, int64_t new0, int64_t n_new, double count, at::Tensor chan_mean,
              at::Tensor chan_var, at::Tensor chan_rstd, const OptT& gamma, const OptT& beta, const OptT& run_mean,
              const OptT& run_var, const OptT& scale, const OptT& shift, int64_t C, double momentum, double eps,
@@ -423,7 +510,12 @@ void register_conv_ops(pybind11::module_& m) {
         pybind11::arg("acc_out") = c10::nullopt, pybind11::arg("k_acc") = c10::nullopt,
         pybind11::arg("k_mean") = c10::nullopt, pybind11::arg("k_rstd") = c10::nullopt,
         pybind11::arg("k_scale") = c10::nullopt, pybind11::arg("k_dgamma") = c10::nullopt,
-        pybind11::arg("k_dbeta") = c10::nullopt, pybind11::arg("k_count") = 0.0);
+        pybind11::arg("k_dbeta") = c10::nullopt, pybind11::arg("k_count") = 0.0,
+        pybind11::arg("tail_counters") = c10::nullopt, pybind11::arg("tail_mode") = 0, pybind11::arg("tail_count") = 0.0,
+        pybind11::arg("tail_mean") = c10::nullopt, pybind11::arg("tail_rstd") = c10::nullopt,
+        pybind11::arg("tail_scale") = c10::nullopt, pybind11::arg("tail_dgamma") = c10::nullopt,
+        pybind11::arg("tail_dbeta") = c10::nullopt, pybind11::arg("tail_k0") = c10::nullopt,
+        pybind11::arg("tail_k1") = c10::nullopt, pybind11::arg("tail_k2") = c10::nullopt);
   m.def("conv_fwd_fused", &conv_fwd_fused, "forward conv with fused batch-norm statistics (accumulator in / out)");
   m.attr("STAT_REPLICAS") = pybind11::int_(ddl::kStatReplicas);
   m.def("bn_acc_finalize", &bn_acc_finalize, "accumulators -> channel mean / var / rstd");
@@ -434,6 +526,11 @@ void register_conv_ops(pybind11::module_& m) {
         pybind11::arg("k_acc") = c10::nullopt, pybind11::arg("k_mean") = c10::nullopt,
         pybind11::arg("k_rstd") = c10::nullopt, pybind11::arg("k_scale") = c10::nullopt, pybind11::arg("k_count") = 0.0,
         pybind11::arg("queue") = nullptr, pybind11::arg("force_sub") = 0);
+  m.def("conv_wgrad_group", &conv_wgrad_group, "weight gradients of up to 24 dense layers in one launch",
+        pybind11::arg("taps"), pybind11::arg("d0"), pybind11::arg("d1"), pybind11::arg("ds0"), pybind11::arg("ds1"),
+        pybind11::arg("ds2"), pybind11::arg("a0"), pybind11::arg("as0"), pybind11::arg("as2"), pybind11::arg("dW"),
+        pybind11::arg("M"), pybind11::arg("H"), pybind11::arg("W"), pybind11::arg("queue"));
+  m.attr("MAX_WGRAD_GROUP") = pybind11::int_(ddl::kMaxWgradGroup);
   pybind11::class_<SlabQueue>(m, "SlabQueue")
       .def(pybind11::init<>())
       .def("flush", &SlabQueue::flush)

@@ -156,11 +156,68 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16 (&
         float s = 0.f;
 #pragma unroll
         for (int g = 0; g < RG; ++g) s += red[(which * RG + g) * BN + cc];
-        if ((KIND == 0 || KIND == 2) && p.bn.acc_out != nullptr) {   // fused statistics: fixed-point integer atomics
+        if (p.bn.acc_out != nullptr) {   // fused statistics: fixed-point integer atomics
           __hip_atomic_fetch_add(p.bn.acc_out + (long)(2 * (tile_x & (kStatReplicas - 1)) + which) * p.bn.acc_out_ld + n0 + cc,
-                                 __double2ll_rn((double)s * (KIND == 2 ? kGradStatScale : kStatScale)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                 __double2ll_rn((double)s * (KIND >= 2 ? kGradStatScale : kStatScale)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
           p.stats_out[((long)tile_x * 2 + which) * p.N + n0 + cc] = s;
+        }
+      }
+    }
+  }
+  // ---- BN-backward bookkeeping by the last-arriving workgroup of this column tile (TailPrep) -----------------
+  if ((KIND == 2 || KIND == 3) && p.tail.counters != nullptr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's statistics atomics are out
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      // Everything the last arriver reads from its peers - the statistics accumulators - was written with
+      // agent-scope ATOMICS and is read back with agent-scope atomic loads: both are performed at the device's
+      // coherence point, never in a per-XCD L2, and every wave waited for the acknowledgement of its atomics
+      // (vmcnt(0) above) before this ticket.  So no release / acquire fence is needed - and a release here would
+      // write back the XCD's whole L2 (the megabytes of dBuf this kernel just produced) once per workgroup:
+      // measured +0.6 ms per step (`fence` = 1 keeps that form for the comparison).
+      if (p.tail.fence) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      const unsigned t = __hip_atomic_fetch_add(p.tail.counters + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = t == gridDim.x - 1;
+      if (last) {
+        __hip_atomic_store(p.tail.counters + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        if (p.tail.fence) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      flag[0] = last;
+    }
+    __syncthreads();
+    if (flag[0]) {
+      for (int cc = tid; cc < BN; cc += NT) {
+        const int c = n0 + cc;
+        if (c >= p.N) continue;
+        long long s1 = 0, s2 = 0;
+#pragma unroll
+        for (int r = 0; r < kStatReplicas; ++r) {
+          s1 += __hip_atomic_load(p.bn.acc_out + (long)(2 * r) * p.bn.acc_out_ld + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s2 += __hip_atomic_load(p.bn.acc_out + (long)(2 * r + 1) * p.bn.acc_out_ld + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const double sg = (double)s1 * (1.0 / kGradStatScale), sgx = (double)s2 * (1.0 / kGradStatScale);
+        const double mean = p.tail.mean[c], rstd = p.tail.rstd[c], sc = p.tail.scale[c];
+        const double dgam = rstd * (sgx - mean * sg);
+        const double a = sg * p.tail.inv_count, b = dgam * p.tail.inv_count;
+        const double kk1 = -sc * b * rstd;
+        const double kk2 = -sc * a + sc * b * rstd * mean;
+        p.tail.dbeta[c] += (float)sg;
+        p.tail.dgamma[c] += (float)dgam;
+        if (p.tail.mode == 0) {
+          p.tail.k0[c] = (float)sc;
+          p.tail.k1[c] = (float)kk1;
+          p.tail.k2[c] = (float)kk2;
+        } else {
+          p.tail.k1[c] += (float)kk1;   // NQ
+          p.tail.k2[c] += (float)kk2;   // NP
         }
       }
     }

@@ -82,11 +82,34 @@ struct FusedK {
   float* dbeta;
 };
 
+// BN-backward bookkeeping in the TAIL of the data-gradient kernel that produced its statistics (kinds 2 / 3 with
+// fixed-point accumulators): every workgroup takes a ticket per column tile after its statistics atomics; the
+// last arriver of a column tile turns the accumulated (sum g, sum g*x) of its columns into dgamma / dbeta and the
+// coefficients of dx = k0*g + k1*x + k2 - what a separate bn_bwd_prep launch did between two kernels of the
+// backward chain (2 per dense layer on the critical path; knock-out: 0.64 ms of the 9.0 ms step at batch 30).
+// Hand-off = agent-scope release before the ticket, agent-scope acquire in the last arriver; integer sums, so the
+// result does not depend on the arrival order.
+struct TailPrep {
+  unsigned* counters;   // [column tiles] tickets; zero before the launch, reset by the last arriver (nullptr: off)
+  int mode;             // 0: k0 / k1 / k2 written;  1: deferred dense-block terms  NQ (k1) += , NP (k2) +=
+  int fence;            // 1: agent-scope release / acquire fences around the ticket (comparison only, see conv_common.h)
+  double inv_count;     // 1 / pixels
+  const float* mean;    // forward statistics of this BN
+  const float* rstd;
+  const float* scale;   // gamma * rstd
+  float* dgamma;        // +=
+  float* dbeta;
+  float* k0;
+  float* k1;
+  float* k2;
+};
+
 // out[M x N] (op)= rows(A)[M x taps*C] * W
 struct ConvGemmParams {
   RowSrc a;
   FusedBn bn;
   FusedK fk;
+  TailPrep tail;
   int M, C, N;        // pixels, channels per tap of the row source (GEMM K = taps*C), output channels
   int H, W;           // spatial size (3x3 taps only)
   int taps;           // 1 or 9 (3x3, stride 1, pad 1)
@@ -127,6 +150,33 @@ struct WgradParams {
   int S;
   int sub;            // 1x1: 32-column sub-tiles per workgroup tile (1..4) and the number of channel tiles
   int ctiles;
+};
+
+// layer-grouped weight gradients (conv_wgrad.hip: wgrad_group_kernel): one entry per dense layer; M, N, the
+// leading dimensions, the pixel chunking and the operand form (two dO sources, affine + ReLU activation) are shared
+constexpr int kMaxWgradGroup = 24;
+struct WgradGroupEntry {
+  const float* d0;    // dO sources and their per-channel vectors (dO = ds0*d0 + ds1*d1 + ds2)
+  const float* d1;
+  const float* ds0;
+  const float* ds1;
+  const float* ds2;
+  const float* a0;    // activation source, as0 / as2 its affine (nullptr: identity)
+  const float* as0;
+  const float* as2;
+  float* slabs;       // [S][N][taps*C]
+  int C;
+  int ctiles;         // 1x1: ceil(C / 128)
+  int block0;         // first workgroup of this entry (filled by the launcher)
+  int pad_;
+};
+struct WgradGroupParams {
+  WgradGroupEntry e[kMaxWgradGroup];
+  int n;
+  int M, N, H, W, taps;
+  int S, rows_per_wg;
+  int ld_d0, ld_d1, ld_a0;
+  int a_relu;
 };
 
 // deferred slab reductions: dW += sum over S slabs, many weight gradients in one launch (conv_wgrad.hip)

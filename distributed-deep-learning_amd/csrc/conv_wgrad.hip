@@ -117,16 +117,15 @@ __device__ __forceinline__ bool xcd_group(int id, int T, int S, int& t, int& chu
 // grid = (c tiles x n tiles x S), XCD-grouped.
 // ---------------------------------------------------------------------------------------------
 template <int SUB, bool DTWO, int PF>
-__global__ void __launch_bounds__(256, 2) wgrad1x1_kernel(const WgradParams p) {
+__device__ __forceinline__ void wgrad1x1_body(const WgradParams& p, const int bid, float* smem) {
   constexpr int TC = 32 * SUB;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ds = smem;                     // [2][RK][128]
   float* As = smem + 2 * RK * 128;      // [2][RK][TC]
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar wave index
   const int li = lane & 31, lh = lane >> 5;
   const int ctiles = p.ctiles, ntiles = (p.N + 127) / 128;
   int t_idx, chunk;
-  if (!xcd_group(blockIdx.x, ctiles * ntiles, p.S, t_idx, chunk)) return;     // grid padded to 8 chunks
+  if (!xcd_group(bid, ctiles * ntiles, p.S, t_idx, chunk)) return;     // grid padded to 8 chunks
   const int c0 = (t_idx % ctiles) * TC, n0 = (t_idx / ctiles) * 128;
   const int mb = chunk * p.rows_per_wg;
   int me = mb + p.rows_per_wg;
@@ -257,13 +256,18 @@ __global__ void __launch_bounds__(256, 2) wgrad1x1_kernel(const WgradParams p) {
   }
 }
 
+template <int SUB, bool DTWO, int PF>
+__global__ void __launch_bounds__(256, 2) wgrad1x1_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  wgrad1x1_body<SUB, DTWO, PF>(p, (int)blockIdx.x, smem);
+}
+
 // ---------------------------------------------------------------------------------------------
 // 3x3 (stride 1, pad 1), N = 32 output channels, C = 128 input channels per workgroup column
 // tile.  grid = (S, 3 (dy), C/128).  Wave w owns channels [32w, 32w+32) for the three dx taps.
 // ---------------------------------------------------------------------------------------------
 template <bool DTWO>
-__global__ void __launch_bounds__(256) wgrad3x3_kernel(const WgradParams p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void wgrad3x3_body(const WgradParams& p, const int bid, float* smem) {
   constexpr int AR = RK + 2;                       // activation rows staged per step (dx halo)
   float* Ds = smem;                                // [2][RK][32]
   float* As = smem + 2 * RK * 32;                  // [2][AR][128]
@@ -272,7 +276,7 @@ __global__ void __launch_bounds__(256) wgrad3x3_kernel(const WgradParams p) {
   const int li = lane & 31, lh = lane >> 5;
   const int ctiles = (p.C + 127) / 128;
   int t_idx, chunk;
-  if (!xcd_group(blockIdx.x, 3 * ctiles, p.S, t_idx, chunk)) return;          // grid padded to 8 chunks
+  if (!xcd_group(bid, 3 * ctiles, p.S, t_idx, chunk)) return;          // grid padded to 8 chunks
   const int dy = t_idx % 3 - 1;
   const int cbase = (t_idx / 3) * 128;
   const int HW = p.H * p.W;
@@ -370,6 +374,47 @@ __global__ void __launch_bounds__(256) wgrad3x3_kernel(const WgradParams p) {
       if (n < p.N && c < p.C) slab[(long)n * KC + (long)tap * p.C + c] = acc[t][r];
     }
   }
+}
+
+template <bool DTWO>
+__global__ void __launch_bounds__(256) wgrad3x3_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  wgrad3x3_body<DTWO>(p, (int)blockIdx.x, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Layer-grouped weight gradients.  The weight gradients of a dense layer feed nothing downstream, and everything
+// they read (the layer's g2 / h / BN coefficients, its slice of the block's gradient buffer, the block buffer)
+// stays valid until the end of the block's backward.  For the small feature maps (14x14, 7x7) one layer's
+// weight gradient is a 10-25 us kernel that is all ramp-up, latency and slab traffic (PMC: 16-30 % MFMA
+// utilisation, 40-50 % of the wave time waiting); G layers in ONE launch give every workgroup a long pixel loop
+// (no 100-way split of 5880 pixels), a few hundred workgroups of real work and G times fewer launches.
+// Workgroup -> (layer entry, tile, pixel chunk); entries share M, N, the leading dimensions and the chunking.
+// ---------------------------------------------------------------------------------------------
+template <int TAPS>
+__global__ void __launch_bounds__(256, 2) wgrad_group_kernel(const WgradGroupParams g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int e = 0;
+  while (e + 1 < g.n && (int)blockIdx.x >= g.e[e + 1].block0) ++e;             // scalar walk over <= 24 entries
+  const WgradGroupEntry en = g.e[e];
+  const int dch = TAPS == 1 ? g.N : g.N;           // dO channels
+  const int ach = en.C;                            // activation channels
+  WgradParams p;
+  p.fk.acc = nullptr; p.fk.acc_ld = 0; p.fk.mean = nullptr; p.fk.rstd = nullptr; p.fk.scale = nullptr;
+  p.fk.inv_count = 0.0; p.fk.dgamma = nullptr; p.fk.dbeta = nullptr;
+  p.d.X0 = en.d0; p.d.X1 = en.d1; p.d.s0 = en.ds0; p.d.s1 = en.ds1; p.d.s2 = en.ds2;
+  p.d.ld0 = g.ld_d0; p.d.ld1 = g.ld_d1; p.d.relu = 0;
+  p.d.bytes0 = (unsigned)((((long)g.M - 1) * g.ld_d0 + dch) * 4);
+  p.d.bytes1 = (unsigned)((((long)g.M - 1) * g.ld_d1 + dch) * 4);
+  p.a.X0 = en.a0; p.a.X1 = nullptr; p.a.s0 = en.as0; p.a.s1 = nullptr; p.a.s2 = en.as2;
+  p.a.ld0 = g.ld_a0; p.a.ld1 = 0; p.a.relu = g.a_relu;
+  p.a.bytes0 = (unsigned)((((long)g.M - 1) * g.ld_a0 + ach) * 4);
+  p.a.bytes1 = 0;
+  p.M = g.M; p.C = en.C; p.N = g.N; p.H = g.H; p.W = g.W; p.taps = TAPS;
+  p.rows_per_wg = g.rows_per_wg; p.slabs = en.slabs; p.S = g.S; p.sub = 4; p.ctiles = en.ctiles;
+  const int bid = (int)blockIdx.x - en.block0;
+  if (TAPS == 1) wgrad1x1_body<4, true, 1>(p, bid, smem);
+  else wgrad3x3_body<true>(p, bid, smem);
 }
 
 // dW[e] += sum_s slabs[s][e] for a whole LIST of weight gradients in one launch: the dense-block backward queues
@@ -478,6 +523,37 @@ void launch_wgrad(const WgradParams& p, hipStream_t s) {
     if (two) hipLaunchKernelGGL(wgrad3x3_kernel<true>, grid, dim3(256), lds3, s, p);
     else hipLaunchKernelGGL(wgrad3x3_kernel<false>, grid, dim3(256), lds3, s, p);
   }
+}
+
+// grouped launch: fills block0 of every entry (workgroups per entry = tiles x 8 x ceil(S / 8), XCD-grouped)
+void launch_wgrad_group(WgradGroupParams& g, hipStream_t s) {
+  static bool attr = false;
+  // DDL_WGRAD_GROUP_LDS1 / _LDS9: LDS bytes REQUESTED per workgroup (>= what the kernel uses).  Asking for more
+  // lowers the number of co-resident weight-gradient workgroups per CU, which leaves LDS / registers for the
+  // (latency-critical) data-gradient chain that runs beside them.
+  static const size_t want1 = [] { const char* e = getenv("DDL_WGRAD_GROUP_LDS1"); return e ? (size_t)atol(e) : 0; }();
+  static const size_t want9 = [] { const char* e = getenv("DDL_WGRAD_GROUP_LDS9"); return e ? (size_t)atol(e) : 0; }();
+  size_t lds1 = (size_t)2 * RK * (128 + 128) * sizeof(float);
+  size_t lds3 = (size_t)(2 * RK * 32 + 2 * (RK + 2) * 128 + 2 * RK) * sizeof(float);
+  if (want1 > lds1) lds1 = want1;
+  if (want9 > lds3) lds3 = want9;
+  if (!attr) {
+    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel<1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel<9>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+    attr = true;
+  }
+  if (g.n <= 0) return;
+  long blocks = 0;
+  const int s8 = 8 * ((g.S + 7) / 8);
+  for (int i = 0; i < g.n; ++i) {
+    g.e[i].block0 = (int)blocks;
+    const int tiles = g.taps == 1 ? g.e[i].ctiles * ((g.N + 127) / 128) : 3 * ((g.e[i].C + 127) / 128);
+    blocks += (long)tiles * s8;
+  }
+  if (g.taps == 1) hipLaunchKernelGGL(wgrad_group_kernel<1>, dim3((unsigned)blocks), dim3(256), lds1, s, g);
+  else hipLaunchKernelGGL(wgrad_group_kernel<9>, dim3((unsigned)blocks), dim3(256), lds3, s, g);
 }
 
 // one launch for up to kMaxSlabEntries queued (slabs, S, total4, dW) reductions; block0 is filled here

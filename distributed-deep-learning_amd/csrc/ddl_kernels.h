@@ -45,6 +45,7 @@ void launch_conv3x3_halo(const ConvGemmParams& p, int bm, hipStream_t s);
 int wgrad_rows_per_wg(int M, int other_grid, int min_rows, int target_wgs);
 void wgrad1x1_tiling(int M, int C, int N, int force_sub, int& sub, int& ctiles);
 void launch_wgrad(const WgradParams& p, hipStream_t s);                      // writes the slabs only
+void launch_wgrad_group(WgradGroupParams& g, hipStream_t s);                // <= 24 layers in one launch, slabs only
 void launch_slab_reduce_multi(SlabReduceParams& p, hipStream_t s);           // dW += sum of slabs, <= 64 entries
 // ---- bn_kernels.hip --------------------------------------------------------------------
 void launch_bn_prep(const float* partials, int G, int ldp, int new0, int n_new, double count,

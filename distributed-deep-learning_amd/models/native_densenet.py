@@ -166,6 +166,16 @@ class _BlockFn(torch.autograd.Function):
         # into the gradient arena (2 slab_reduce launches per layer otherwise: 116 of the step's 660 graph nodes)
         defer = unit.stage.defer_slab_reduce          # "block" | "layer" | "" (reduce behind every kernel)
         wq = dict(queue=ext.SlabQueue()) if defer else {}
+        G = unit.stage.wgrad_group_size(M)
+        if G > 1 and not fused:
+            _backward_grouped(ext, unit, G, main, side, d2d, buf2d, nq, np_, stats, sc1, sh1, bn2, h,
+                                       M, H, W, C0, L, bf)
+            if side is not None:
+                unit.stage.join(main, side)
+            dx = torch.empty(B, H, W, C0, **f32)
+            ext.rows_op(4, M, d2d[:, :C0], buf2d[:, :C0], nq, np_, dx.view(M, C0), H, W, False)
+            unit.stage._unit_grads_ready(unit)
+            return dx, None, None
         for l in range(L - 1, -1, -1):
             lay = unit.layers[l]
             C = C0 + GROWTH * l
@@ -233,6 +243,92 @@ class _BlockFn(torch.autograd.Function):
         ext.rows_op(4, M, d2d[:, :C0], buf2d[:, :C0], nq, np_, dx.view(M, C0), H, W, False)
         unit.stage._unit_grads_ready(unit)
         return dx, None, None
+
+
+# DDL_KNOCKOUT=wgrad|bnprep: leave a kernel class OUT of the grouped dense-block backward (results are wrong - this is
+# the timing experiment that shows what the step's wall clock depends on; README "What the step is made of")
+_KNOCK = os.environ.get("DDL_KNOCKOUT", "")
+
+
+def _backward_grouped(ext, unit, G, main, side, d2d, buf2d, nq, np_, stats, sc1, sh1, bn2, h, M, H, W, C0, L, bf):
+    """Dense-block backward with LAYER-GROUPED weight gradients (csrc/conv_wgrad.hip: wgrad_group_kernel).
+
+    The data-gradient chain runs layer by layer as always; the weight gradients of G consecutive layers are issued
+    as two launches (all 3x3, all 1x1) + one slab reduction on the side stream once the chain has produced the
+    group's g2 / k - everything else they read stays valid to the end of the block: layer l's slice of dBuf and of
+    the deferred-term vectors nq / np is final when its turn comes and later (lower) layers only touch channels
+    below it.  g2 / k live in two sets of G buffers, so the side stream may work on one group while the chain fills
+    the other."""
+    f32 = dict(dtype=torch.float32, device=buf2d.device)
+    ones = unit.stage.ones
+    k = torch.empty(2, G, 3, MID, **f32)
+    g2 = torch.empty(2, G, M, MID, **f32)
+    done = [None, None]
+    grp, gi = [], 0
+    tail = unit.stage.tail_prep
+    if tail:
+        # BN-backward bookkeeping in the tail of the data-gradient kernels (csrc/conv_params.h TailPrep): statistics
+        # go to fixed-point accumulators, the last-arriving workgroup of a column tile derives dgamma / dbeta and the
+        # coefficients - no bn_bwd_prep launch between two kernels of the chain.  One zero-fill for the whole block.
+        Cf = buf2d.shape[1]
+        R = ext.STAT_REPLICAS
+        acc = torch.zeros(L, R, 2, MID + Cf, dtype=torch.int64, device=buf2d.device)
+        tickets = torch.zeros(L, 2, 32, dtype=torch.int32, device=buf2d.device)
+
+    def launch(group, set_):
+        if _KNOCK == "wgrad":
+            return
+        q = ext.SlabQueue()
+        sls = [slice(C0 + GROWTH * l, C0 + GROWTH * (l + 1)) for l in group]
+        lays = [unit.layers[l] for l in group]
+        n = len(group)
+        ext.conv_wgrad_group(9, [d2d[:, s] for s in sls], [buf2d[:, s] for s in sls], [ones[:GROWTH]] * n,
+                             [nq[s] for s in sls], [np_[s] for s in sls], [h[l] for l in group],
+                             [bn2[l, 3] for l in group], [bn2[l, 4] for l in group], [a.gw2 for a in lays], M, H, W, q)
+        ext.conv_wgrad_group(1, [g2[set_, i] for i in range(n)], [h[l] for l in group], [k[set_, i, 0] for i in range(n)],
+                             [k[set_, i, 1] for i in range(n)], [k[set_, i, 2] for i in range(n)],
+                             [buf2d[:, :C0 + GROWTH * l] for l in group], [sc1[l] for l in group], [sh1[l] for l in group],
+                             [a.gw1 for a in lays], M, H, W, q)
+        q.flush()
+
+    for l in range(L - 1, -1, -1):
+        lay = unit.layers[l]
+        C = C0 + GROWTH * l
+        sl = slice(C, C + GROWTH)
+        set_, slot = gi % 2, len(grp)
+        if slot == 0 and side is not None and done[set_] is not None:
+            main.wait_event(done[set_])              # the side stream has finished with this buffer set
+        sc2, sh2 = bn2[l, 3], bn2[l, 4]
+        t3 = t1 = {}
+        if tail:
+            t3 = dict(acc_out=acc[l, :, :, :MID], tail_counters=tickets[l, 0], tail_mode=0, tail_count=float(M),
+                      tail_mean=bn2[l, 0], tail_rstd=bn2[l, 2], tail_scale=sc2, tail_dgamma=lay.gg2, tail_dbeta=lay.gb2,
+                      tail_k0=k[set_, slot, 0], tail_k1=k[set_, slot, 1], tail_k2=k[set_, slot, 2])
+            t1 = dict(acc_out=acc[l, :, :, MID:MID + C], tail_counters=tickets[l, 1], tail_mode=1, tail_count=float(M),
+                      tail_mean=stats[0], tail_rstd=stats[2], tail_scale=sc1[l], tail_dgamma=lay.gg1, tail_dbeta=lay.gb1,
+                      tail_k1=nq, tail_k2=np_)
+        st = ext.conv_gemm(d2d[:, sl], buf2d[:, sl], ones[:GROWTH], nq[sl], np_[sl], False, M, H, W, 9, True,
+                           lay.w2, True, g2[set_, slot], True, False, h[l], sc2, sh2, 2, 0, bf, **t3)
+        if not tail and _KNOCK != "bnprep":
+            ext.bn_bwd_prep(st, float(M), bn2[l, 0], bn2[l, 2], sc2, lay.gg2, lay.gb2,
+                            k[set_, slot, 0], k[set_, slot, 1], k[set_, slot, 2], MID, 0)
+        st1 = ext.conv_gemm(g2[set_, slot], h[l], k[set_, slot, 0], k[set_, slot, 1], k[set_, slot, 2], False, M, H, W, 1,
+                            False, lay.w1, True, d2d[:, :C], True, True, buf2d[:, :C], sc1[l], sh1[l], 2, 0, bf, **t1)
+        if not tail and _KNOCK != "bnprep":
+            ext.bn_bwd_prep(st1, float(M), stats[0], stats[2], sc1[l], lay.gg1, lay.gb1, None, nq, np_, C, 1)
+        grp.append(l)
+        if len(grp) == G or l == 0:
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    launch(grp, set_)
+                    done[set_] = torch.cuda.Event()
+                    done[set_].record(side)
+            else:
+                launch(grp, set_)
+            grp, gi = [], gi + 1
 
 
 class _Layer:
@@ -532,6 +628,8 @@ class NativeDenseNetStage(nn.Module):
         self.anchor = torch.zeros(1, device=device, requires_grad=True)   # keeps every unit in the graph
         self.side_stream = torch.cuda.Stream(device)
         self.overlap_wgrad = True
+        self._wgrad_group = os.environ.get("DDL_WGRAD_GROUP", "auto")
+        self.tail_prep = os.environ.get("DDL_TAIL_PREP", "1") == "1"      # csrc/conv_params.h TailPrep (grouped backward)
         self._fork_origin = None          # origin stream of the open side-stream fork (see ``fork``)
         self._owned_grad_ptr = 0          # data_ptr of the gradient a transition / head backward just produced
         self.ones = torch.ones(1024, device=device)
@@ -599,6 +697,15 @@ class NativeDenseNetStage(nn.Module):
 
     def bv(self, fqn: str) -> torch.Tensor:
         return self._buffers_by_name[fqn]
+
+    def wgrad_group_size(self, M: int) -> int:
+        """Dense layers whose weight gradients share one launch (``_backward_grouped``).  ``DDL_WGRAD_GROUP``: an
+        integer, or ``auto`` - group on the small feature maps, where a single layer's weight gradient is a
+        latency-bound 10-25 us kernel; keep the per-layer kernels where one layer already fills the chip."""
+        g = self._wgrad_group
+        if g == "auto":
+            return 4
+        return max(1, min(int(g), 24))
 
     # ---- side-stream discipline ------------------------------------------------------------
     # Ending a HIP stream capture whose nested fork rejoins the origin only THROUGH an intermediate stream
