@@ -142,8 +142,19 @@ class _BlockFn(torch.autograd.Function):
         unit.stage._owned_grad_ptr = 0
         d2d = dbuf.view(M, Cf)
         buf2d = buf.view(M, Cf)
-        nq = torch.zeros(Cf, **f32)           # deferred terms: dX = dBuf + nq * x + np
-        np_ = torch.zeros(Cf, **f32)
+        # deferred terms dX = dBuf + nq * x + np, and (grouped backward) the statistics accumulators + arrival
+        # tickets of the data-gradient kernels' tail bookkeeping: ONE zero-fill for all of them
+        fused = unit.stage.fused_bwd
+        G = unit.stage.wgrad_group_size(M)
+        grouped = G > 1 and not fused
+        R = ext.STAT_REPLICAS
+        n_acc = L * R * 2 * (MID + Cf) if (grouped and unit.stage.tail_prep) else 0
+        n_tick = L * 2 * 32 if n_acc else 0
+        zero = torch.zeros(8 * n_acc + 4 * (2 * Cf + n_tick), dtype=torch.uint8, device=buf.device)
+        acc = zero[:8 * n_acc].view(torch.int64).view(L, R, 2, MID + Cf) if n_acc else None
+        fz = zero[8 * n_acc:].view(torch.float32)
+        nq, np_ = fz[:Cf], fz[Cf:2 * Cf]
+        tickets = fz[2 * Cf:].view(torch.int32).view(L, 2, 32) if n_acc else None
         ones = unit.stage.ones
         # Weight gradients feed nothing downstream, so they run on a side stream beside the
         # data-gradient chain (parallel branches once the step is captured into a hipGraph).
@@ -159,17 +170,15 @@ class _BlockFn(torch.autograd.Function):
         done = [None] * NB
         min_rows = unit.stage.wgrad_min_rows
         bf = unit.stage.bf16
-        fused = unit.stage.fused_bwd
         if fused:     # (sum g2, sum g2*h) accumulators: BN2-backward coefficients are derived by their consumers
             acc_g = torch.zeros(L, ext.STAT_REPLICAS, 2, MID, dtype=torch.int64, device=buf.device)
         # every layer's weight-gradient kernels leave partial slabs; ONE launch at the end of the block adds them
         # into the gradient arena (2 slab_reduce launches per layer otherwise: 116 of the step's 660 graph nodes)
         defer = unit.stage.defer_slab_reduce          # "block" | "layer" | "" (reduce behind every kernel)
         wq = dict(queue=ext.SlabQueue()) if defer else {}
-        G = unit.stage.wgrad_group_size(M)
-        if G > 1 and not fused:
+        if grouped:
             _backward_grouped(ext, unit, G, main, side, d2d, buf2d, nq, np_, stats, sc1, sh1, bn2, h,
-                                       M, H, W, C0, L, bf)
+                              M, H, W, C0, L, bf, acc, tickets)
             if side is not None:
                 unit.stage.join(main, side)
             dx = torch.empty(B, H, W, C0, **f32)
@@ -250,7 +259,8 @@ class _BlockFn(torch.autograd.Function):
 _KNOCK = os.environ.get("DDL_KNOCKOUT", "")
 
 
-def _backward_grouped(ext, unit, G, main, side, d2d, buf2d, nq, np_, stats, sc1, sh1, bn2, h, M, H, W, C0, L, bf):
+def _backward_grouped(ext, unit, G, main, side, d2d, buf2d, nq, np_, stats, sc1, sh1, bn2, h, M, H, W, C0, L, bf,
+                      acc, tickets):
     """Dense-block backward with LAYER-GROUPED weight gradients (csrc/conv_wgrad.hip: wgrad_group_kernel).
 
     The data-gradient chain runs layer by layer as always; the weight gradients of G consecutive layers are issued
@@ -265,15 +275,10 @@ def _backward_grouped(ext, unit, G, main, side, d2d, buf2d, nq, np_, stats, sc1,
     g2 = torch.empty(2, G, M, MID, **f32)
     done = [None, None]
     grp, gi = [], 0
-    tail = unit.stage.tail_prep
-    if tail:
-        # BN-backward bookkeeping in the tail of the data-gradient kernels (csrc/conv_params.h TailPrep): statistics
-        # go to fixed-point accumulators, the last-arriving workgroup of a column tile derives dgamma / dbeta and the
-        # coefficients - no bn_bwd_prep launch between two kernels of the chain.  One zero-fill for the whole block.
-        Cf = buf2d.shape[1]
-        R = ext.STAT_REPLICAS
-        acc = torch.zeros(L, R, 2, MID + Cf, dtype=torch.int64, device=buf2d.device)
-        tickets = torch.zeros(L, 2, 32, dtype=torch.int32, device=buf2d.device)
+    # BN-backward bookkeeping in the tail of the data-gradient kernels (csrc/conv_params.h TailPrep): statistics go
+    # to fixed-point accumulators (`acc`, zeroed by the caller together with nq / np), the last-arriving workgroup
+    # of a column tile derives dgamma / dbeta and the coefficients - no bn_bwd_prep launch between two kernels.
+    tail = acc is not None
 
     def launch(group, set_):
         if _KNOCK == "wgrad":
