@@ -175,8 +175,21 @@ def main_split_explorer(argv=None):
     p = argparse.ArgumentParser(prog="debug.py")
     p.add_argument("--split-points", nargs="*", default=None)
     p.add_argument("--num-classes", type=int, default=1000)      # debug.py uses the stock 1000-class model
+    p.add_argument("--auto-stages", type=int, nargs="*", default=[], help="also derive balanced splits for these stage "
+                   "counts (models/split.py; on a GPU from measured unit times, and the stages are timed)")
+    p.add_argument("--micro-batch", type=int, default=6)
     a = p.parse_args(argv)
     specs = [a.split_points] if a.split_points is not None else [default_split_points(n) for n in (2, 4)]
+    if a.auto_stages:
+        from .models import split
+        dev = torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")
+        for n in a.auto_stages:
+            pts, costs = split.auto_split_points(n, dev, a.micro_batch)
+            print(f"auto split, {n} stages (unit costs {[round(c, 3) for c in costs]}): {pts}")
+            if dev.type == "cuda":
+                print(f"  measured stage forward+backward ms at micro-batch {a.micro_batch}: "
+                      f"{[round(t, 3) for t in split.measure_stage_times(pts, dev, a.micro_batch)]}")
+            specs.append(pts)
     total = sum(q.numel() for q in densenet121(a.num_classes).parameters())
     print(f"Model parameters: {total}")
     out = []

@@ -207,7 +207,8 @@ void launch_bn_bwd_prep(const float* partials, int G, int ldp, double count, con
 // ---------------------------------------------------------------------------------------------
 // rows_op: pixel-touching glue with optional per-channel partial sums.
 //   workgroup = ROWS_PER_WG rows x all C channels; thread = one float4 channel column
-//   (C/4 columns, 256/(C/4) row lanes; C in {64,128,256,512,1024} -> needs C/4 <= 256).
+//   (C/4 columns, floor(256/(C/4)) row lanes - the threads past lanes*C/4 idle; any C % 4 == 0 with C/4 <= 256:
+//   a pipeline stage that starts inside a dense block copies in 96, 160, ... channels).
 // modes:
 //   0 COPY_STATS : out[m*ldo+c] = in[m*ldi+c];                      stats (v, v*v)
 //   1 POOL_FWD   : out[mp][c] = 0.25 * sum_{2x2} relu(sc*x+sh)      (rows = pooled pixels)

@@ -458,7 +458,7 @@ at::Tensor rows_op(int64_t mode, int64_t M, const at::Tensor& in, const OptT& x,
   ddl::DeviceGuard guard(in.device());
   const int64_t C = out.size(1);
   TORCH_CHECK(mode >= 0 && mode <= 4, "rows_op mode");
-  TORCH_CHECK(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, "rows_op: C must be 4*2^k <= 1024");
+  TORCH_CHECK(C % 4 == 0 && C / 4 <= 256, "rows_op: C must be a multiple of 4, <= 1024");
   check_rows(out, "out", M, C);
   int64_t in_rows = M;
   if (mode == 1) { TORCH_CHECK(H % 2 == 0 && W % 2 == 0 && M % ((H / 2) * (W / 2)) == 0, "pool fwd geometry"); in_rows = 0; }

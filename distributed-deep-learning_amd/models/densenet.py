@@ -14,6 +14,12 @@ units - ``stem, denseblock1, transition1, ..., denseblock4, head`` - and a stage
 a contiguous run of units.  Exactly one tensor crosses every unit boundary, which
 is the property the reference found it needed (debug.py:9,20: splitting inside a
 block or at block ENDs ships every skip tensor and was 3x slower).
+
+A dense block may itself be cut between two of its layers: the unit ``denseblock3[8:24]`` is
+layers 9..24 of block 3.  What crosses such a boundary is still ONE tensor - the concatenated
+feature map of everything before it (in the native engine that is literally one NHWC buffer) -
+so the fx tracer's "skip connections" problem (debug.py:9) does not arise, and pipeline stages
+can be balanced at layer granularity (``models/split.py``), not just at the nine unit borders.
 """
 from __future__ import annotations
 
@@ -31,6 +37,67 @@ INIT_FEATURES = 64
 
 UNIT_NAMES = ("stem", "denseblock1", "transition1", "denseblock2", "transition2",
               "denseblock3", "transition3", "denseblock4", "head")
+
+
+def parse_unit(unit: str) -> Tuple[str, int, int]:
+    """``(base, first layer, end layer)`` of a unit name; layers are only meaningful for dense blocks
+    (``denseblock3`` = ``("denseblock3", 0, 24)``, ``denseblock3[8:24]`` = ``("denseblock3", 8, 24)``)."""
+    base, l0, l1 = unit, 0, 0
+    if "[" in unit:
+        base, rng = unit[:-1].split("[")
+        a, b = rng.split(":")
+        l0, l1 = int(a), int(b)
+    if base not in UNIT_NAMES:
+        raise ValueError(f"unknown unit {unit!r}")
+    if base.startswith("denseblock"):
+        n = BLOCK_CONFIG[int(base[-1]) - 1]
+        if "[" not in unit:
+            l0, l1 = 0, n
+        if not 0 <= l0 < l1 <= n:
+            raise ValueError(f"bad layer range in {unit!r} (block has {n} layers)")
+    elif "[" in unit:
+        raise ValueError(f"only dense blocks have layer ranges: {unit!r}")
+    return base, l0, l1
+
+
+def unit_name(base: str, l0: int = 0, l1: int = 0) -> str:
+    if base.startswith("denseblock") and (l0, l1) != (0, BLOCK_CONFIG[int(base[-1]) - 1]):
+        return f"{base}[{l0}:{l1}]"
+    return base
+
+
+def model_atoms() -> List[Tuple[str, int]]:
+    """The model as its smallest stage-able pieces, in order: ``(unit, layer)`` - one atom per dense layer, one
+    per other unit (layer = 0).  A pipeline stage is a contiguous run of atoms."""
+    out: List[Tuple[str, int]] = []
+    for u in UNIT_NAMES:
+        if u.startswith("denseblock"):
+            out += [(u, l) for l in range(BLOCK_CONFIG[int(u[-1]) - 1])]
+        else:
+            out.append((u, 0))
+    return out
+
+
+def atoms_to_units(atoms: Sequence[Tuple[str, int]]) -> Tuple[str, ...]:
+    """Merge a contiguous run of atoms into unit names (consecutive layers of a block become one unit)."""
+    units: List[str] = []
+    i = 0
+    while i < len(atoms):
+        base, l = atoms[i]
+        j = i
+        while j + 1 < len(atoms) and atoms[j + 1][0] == base and base.startswith("denseblock"):
+            j += 1
+        units.append(unit_name(base, l, atoms[j][1] + 1) if base.startswith("denseblock") else base)
+        i = j + 1
+    return tuple(units)
+
+
+def unit_atoms(units: Sequence[str]) -> List[Tuple[str, int]]:
+    out: List[Tuple[str, int]] = []
+    for u in units:
+        base, l0, l1 = parse_unit(u)
+        out += [(base, l) for l in range(l0, l1)] if base.startswith("denseblock") else [(base, 0)]
+    return out
 
 
 def block_channels() -> List[Tuple[int, int]]:
@@ -59,9 +126,12 @@ class _DenseLayer(nn.Module):
 
 
 class _DenseBlock(nn.ModuleDict):
-    def __init__(self, num_layers: int, c_in: int) -> None:
+    """Layers ``first .. first+num_layers-1`` of a dense block (the whole block by default); ``c_in`` is the width
+    of the block's input, the layer names keep their position in the full block."""
+
+    def __init__(self, num_layers: int, c_in: int, first: int = 0) -> None:
         super().__init__()
-        for i in range(num_layers):
+        for i in range(first, first + num_layers):
             self[f"denselayer{i + 1}"] = _DenseLayer(c_in + i * GROWTH)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -103,9 +173,11 @@ class DenseNetStage(nn.Module):
     def __init__(self, units: Sequence[str] = UNIT_NAMES, num_classes: int = 5) -> None:
         super().__init__()
         units = tuple(units)
-        idx = [UNIT_NAMES.index(u) for u in units]
-        if idx != list(range(idx[0], idx[0] + len(idx))):
-            raise ValueError(f"units must be a contiguous run of {UNIT_NAMES}, got {units}")
+        atoms, mine = model_atoms(), unit_atoms(units)
+        start = atoms.index(mine[0]) if mine and mine[0] in atoms else -1
+        if start < 0 or atoms[start:start + len(mine)] != mine or atoms_to_units(mine) != units:
+            raise ValueError(f"units must be a contiguous run of {UNIT_NAMES} (dense blocks may be cut between "
+                             f"layers: 'denseblock3[8:24]'), got {units}")
         self.units = units
         self.num_classes = num_classes
         chans = block_channels()
@@ -117,8 +189,9 @@ class DenseNetStage(nn.Module):
                 feats["relu0"] = nn.ReLU(inplace=True)
                 feats["pool0"] = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
             elif u.startswith("denseblock"):
-                b = int(u[-1]) - 1
-                feats[u] = _DenseBlock(BLOCK_CONFIG[b], chans[b][0])
+                base, l0, l1 = parse_unit(u)
+                b = int(base[-1]) - 1
+                feats[base] = _DenseBlock(l1 - l0, chans[b][0], first=l0)
             elif u.startswith("transition"):
                 b = int(u[-1]) - 1
                 feats[u] = _Transition(chans[b][1], chans[b][1] // 2)
@@ -159,7 +232,8 @@ class DenseNetStage(nn.Module):
             h = (h + 2 * 1 - 3) // 2 + 1
             return (b, INIT_FEATURES, h, h)
         if unit.startswith("denseblock"):
-            return (b, chans[int(unit[-1]) - 1][1], in_shape[2], in_shape[3])
+            base, _l0, l1 = parse_unit(unit)
+            return (b, chans[int(base[-1]) - 1][0] + GROWTH * l1, in_shape[2], in_shape[3])
         if unit.startswith("transition"):
             return (b, chans[int(unit[-1]) - 1][1] // 2, in_shape[2] // 2, in_shape[3] // 2)
         if unit == "head":
@@ -183,27 +257,39 @@ def densenet121(num_classes: int = 5) -> DenseNetStage:
 # --------------------------------------------------------------------------------------
 # split specs
 # --------------------------------------------------------------------------------------
-def split_point_to_unit(name: str) -> str:
-    """Map a reference-style split point (the module whose BEGINNING starts a new stage,
-    pp.py:383-385, debug.py:36-38) to the unit that starts the stage."""
+def split_point_to_atom(name: str) -> Tuple[str, int]:
+    """Map a reference-style split point - the module whose BEGINNING starts a new stage (pp.py:383-385,
+    debug.py:36-38) - to the atom that starts the stage: a dense block, one of its layers
+    (``features.denseblock3.denselayer9``), a transition, or the head (``features.norm5`` / ``classifier``)."""
     n = name
     if n.startswith("features."):
         n = n[len("features."):]
-    if n.endswith(".denselayer1"):
-        n = n[: -len(".denselayer1")]
+    layer = 0
+    if ".denselayer" in n:
+        n, lay = n.split(".denselayer", 1)
+        if not lay.isdigit():
+            raise ValueError(f"unsupported split point {name!r}: a stage may start at a dense LAYER, not inside one")
+        layer = int(lay) - 1
     if n in ("norm5", "classifier"):
         n = "head"
-    if n in UNIT_NAMES and n != "stem":
-        return n
+    atom = (n, layer)
+    if n in UNIT_NAMES and n != "stem" and atom in model_atoms() and atom != model_atoms()[0]:
+        return atom
     raise ValueError(
-        f"unsupported split point {name!r}: stages may start at a dense block, a transition or the head "
-        f"(exactly one tensor crosses there; mid-block splits ship every skip tensor - reference debug.py:9,20)")
+        f"unsupported split point {name!r}: stages may start at a dense block, a dense layer, a transition or the "
+        f"head (exactly one tensor crosses there)")
+
+
+def split_point_to_unit(name: str) -> str:
+    """Unit that contains the stage start named by a split point (kept for callers that think in units)."""
+    return split_point_to_atom(name)[0]
 
 
 def stage_units(split_points: Sequence[str]) -> List[Tuple[str, ...]]:
-    starts = sorted({UNIT_NAMES.index(split_point_to_unit(s)) for s in split_points})
-    bounds = [0] + starts + [len(UNIT_NAMES)]
-    return [UNIT_NAMES[a:b] for a, b in zip(bounds[:-1], bounds[1:])]
+    atoms = model_atoms()
+    starts = sorted({atoms.index(split_point_to_atom(s)) for s in split_points})
+    bounds = [0] + starts + [len(atoms)]
+    return [atoms_to_units(atoms[a:b]) for a, b in zip(bounds[:-1], bounds[1:])]
 
 
 def default_split_points(num_stages: int) -> List[str]:

@@ -44,7 +44,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..utils.arena import FlatArena, FlatBuffers, reverse_named_parameters
-from .densenet import (BLOCK_CONFIG, BN_SIZE, GROWTH, UNIT_NAMES, DenseNetStage, block_channels)
+from .densenet import (BLOCK_CONFIG, BN_SIZE, GROWTH, UNIT_NAMES, DenseNetStage, block_channels, parse_unit)
 
 BN_MOMENTUM = 0.1
 BN_EPS = 1e-5
@@ -344,10 +344,14 @@ class _Layer:
 
 class BlockUnit:
     def __init__(self, stage: "NativeDenseNetStage", name: str) -> None:
+        # ``name`` may carry a layer range (``denseblock3[8:24]``: a pipeline stage boundary inside the block);
+        # the unit then owns layers l0..l1-1 and its input is the block's buffer prefix of c_in channels
         self.stage, self.name = stage, name
-        b = int(name[-1]) - 1
-        self.num_layers = BLOCK_CONFIG[b]
-        self.c_in, self.c_out = block_channels()[b]
+        self.block, self.l0, self.l1 = parse_unit(name)
+        b = int(self.block[-1]) - 1
+        c0 = block_channels()[b][0]
+        self.num_layers = self.l1 - self.l0
+        self.c_in, self.c_out = c0 + GROWTH * self.l0, c0 + GROWTH * self.l1
         self.layers: List[_Layer] = []
         self.out_stats: Optional[torch.Tensor] = None
         self.param_names: List[str] = []
@@ -355,8 +359,10 @@ class BlockUnit:
     def bind(self) -> None:
         st = self.stage
         self.layers = []
-        for i in range(self.num_layers):
-            pre = f"features.{self.name}.denselayer{i + 1}."
+        prefixes = []
+        for i in range(self.l0, self.l1):
+            pre = f"features.{self.block}.denselayer{i + 1}."
+            prefixes.append(pre)
             lay = _Layer()
             lay.g1, lay.gg1 = st.pv(pre + "norm1.weight")
             lay.b1, lay.gb1 = st.pv(pre + "norm1.bias")
@@ -367,7 +373,7 @@ class BlockUnit:
             lay.rm1, lay.rv1 = st.bv(pre + "norm1.running_mean"), st.bv(pre + "norm1.running_var")
             lay.rm2, lay.rv2 = st.bv(pre + "norm2.running_mean"), st.bv(pre + "norm2.running_var")
             self.layers.append(lay)
-        self.param_names = [n for n in st.param_index if n.startswith(f"features.{self.name}.")]
+        self.param_names = [n for n in st.param_index if n.startswith(tuple(prefixes))]
 
     def __call__(self, x: torch.Tensor, in_stats) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         y = _BlockFn.apply(x, self.stage.anchor, self)
@@ -652,13 +658,21 @@ class NativeDenseNetStage(nn.Module):
         for u in self.unit_objs:
             u.bind()
 
-    @staticmethod
-    def unit_of_param(fqn: str) -> str:
-        """Unit that owns a parameter (torchvision FQN)."""
+    def unit_of_param(self, fqn: str) -> str:
+        """Unit of this stage that owns a parameter (torchvision FQN)."""
         if fqn.startswith("classifier.") or fqn.startswith("features.norm5."):
             return "head"
-        part = fqn.split(".")[1]
-        return "stem" if part in ("conv0", "norm0") else part
+        parts = fqn.split(".")
+        part = parts[1]
+        if part in ("conv0", "norm0"):
+            return "stem"
+        if part.startswith("denseblock"):
+            layer = int(parts[2][len("denselayer"):]) - 1
+            for u in self.units:
+                base, l0, l1 = parse_unit(u)
+                if base == part and l0 <= layer < l1:
+                    return u
+        return part
 
     # ---- layout conversion (checkpoint boundary) -------------------------------------------
     @staticmethod

@@ -3,28 +3,26 @@
 The reference hard-codes its 2-stage split at ``features.denseblock3.denselayer1`` (pp.py:380-386) and tried
 others by hand in debug.py:20-40 (4 stages at block BEGINNINGs: 115 s/epoch, at block ENDs: 334 s/epoch).  With
 that split stage 0 carries 73 % of the multiply-accumulates, so the pipeline runs at the speed of
-its first stage.  Here the stage starts are chosen by an exact search over the unit boundaries (stages are
-contiguous runs of the 9 units and exactly one tensor crosses a boundary - at most C(8, S-1) = 70 candidates)
-that minimises the slowest stage's cost, where a unit's cost is
+its first stage.  Here the stage starts are chosen by an exact linear-partition search over the model's ATOMS -
+every dense layer, transition, the stem and the head (63 pieces; a dense block may be cut between two layers,
+one tensor still crosses: ``models/densenet.py``) - that minimises the slowest stage's cost.  A unit's cost is
 
   * on a GPU: its MEASURED forward + backward time at the micro-batch size of the run.  Every unit forward and
     every unit backward is captured as its own hipGraph (what a stage really replays - eager timings would
     measure Python launch overhead, i.e. the number of kernels, not the kernels) and timed with events over a
     few replays; the vector is averaged over all ranks so that every rank derives the same cut;
   * on the CPU (gloo plumbing tests): the analytic multiply-accumulate count of the unit.
+A dense block's cost is spread over its layers in proportion to their multiply-accumulates plus a per-layer
+constant (the small feature maps are latency-bound: every layer costs about the same there).
 """
 from __future__ import annotations
 
-from itertools import combinations
+import os
 from typing import List, Sequence, Tuple
 
 import torch
 
-from .densenet import BLOCK_CONFIG, BN_SIZE, GROWTH, INIT_FEATURES, UNIT_NAMES, block_channels
-
-# the reference-style name of the module whose BEGINNING starts a stage at unit i (pp.py:383-385)
-_SPLIT_NAME = {u: (f"features.{u}.denselayer1" if u.startswith("denseblock") else
-                   "features.norm5" if u == "head" else f"features.{u}") for u in UNIT_NAMES}
+from .densenet import BLOCK_CONFIG, BN_SIZE, GROWTH, INIT_FEATURES, UNIT_NAMES, block_channels, model_atoms
 
 
 def analytic_unit_macs(image_size: int = 224) -> List[float]:
@@ -54,24 +52,68 @@ def analytic_unit_macs(image_size: int = 224) -> List[float]:
     return out
 
 
+def layer_macs(image_size: int = 224) -> dict:
+    """``{block: [forward multiply-accumulates per image of each layer]}``."""
+    h = ((image_size + 2 * 3 - 7) // 2 + 1 + 2 - 3) // 2 + 1
+    chans, out = block_channels(), {}
+    for b, n in enumerate(BLOCK_CONFIG):
+        out[f"denseblock{b + 1}"] = [float(h * h * ((chans[b][0] + GROWTH * l) * BN_SIZE * GROWTH + 9 * BN_SIZE * GROWTH * GROWTH))
+                                     for l in range(n)]
+        h //= 2
+    return out
+
+
+def atom_costs(unit_costs: Sequence[float], image_size: int = 224, latency_share: float = 0.5) -> List[float]:
+    """Per-atom costs from per-unit costs: a block's cost goes to its layers, ``latency_share`` of it evenly (launch
+    / latency floor of the small layers), the rest in proportion to the layers' multiply-accumulates."""
+    lm = layer_macs(image_size)
+    per_unit = dict(zip(UNIT_NAMES, unit_costs))
+    out = []
+    for u, l in model_atoms():
+        if u.startswith("denseblock"):
+            macs, n = lm[u], len(lm[u])
+            out.append(per_unit[u] * (latency_share / n + (1.0 - latency_share) * macs[l] / sum(macs)))
+        else:
+            out.append(per_unit[u])
+    return out
+
+
 def balanced_starts(costs: Sequence[float], num_stages: int) -> Tuple[int, ...]:
-    """Unit indices that start stages 1..S-1: the partition of ``costs`` into ``num_stages`` contiguous runs with the
-    smallest maximum (ties: the smallest sum of squares, then the earliest cuts - deterministic on every rank)."""
+    """Indices that start stages 1..S-1: the partition of ``costs`` into ``num_stages`` contiguous runs with the
+    smallest maximum (classic linear-partition DP; ties resolve to the earliest cuts - deterministic on every rank)."""
     n = len(costs)
     if not 1 <= num_stages <= n:
-        raise ValueError(f"{n} units cannot make {num_stages} stages")
-    best, best_key = (), None
-    for cuts in combinations(range(1, n), num_stages - 1):
-        bounds = (0,) + cuts + (n,)
-        loads = [sum(costs[a:b]) for a, b in zip(bounds[:-1], bounds[1:])]
-        key = (round(max(loads), 9), round(sum(x * x for x in loads), 9), cuts)
-        if best_key is None or key < best_key:
-            best, best_key = cuts, key
-    return best
+        raise ValueError(f"{n} pieces cannot make {num_stages} stages")
+    pre = [0.0]
+    for c in costs:
+        pre.append(pre[-1] + float(c))
+    INF = float("inf")
+    # best[k][i]: smallest max load splitting the first i pieces into k runs; cut[k][i]: start of the last run
+    best = [[INF] * (n + 1) for _ in range(num_stages + 1)]
+    cut = [[0] * (n + 1) for _ in range(num_stages + 1)]
+    best[0][0] = 0.0
+    for k in range(1, num_stages + 1):
+        for i in range(k, n + 1):
+            for j in range(k - 1, i):
+                v = max(best[k - 1][j], pre[i] - pre[j])
+                if v < best[k][i] - 1e-12:
+                    best[k][i], cut[k][i] = v, j
+    starts, i = [], n
+    for k in range(num_stages, 1, -1):
+        i = cut[k][i]
+        starts.append(i)
+    return tuple(reversed(starts))
 
 
 def starts_to_split_points(starts: Sequence[int]) -> List[str]:
-    return [_SPLIT_NAME[UNIT_NAMES[i]] for i in starts]
+    """Atom indices -> the reference's split-point names (module whose BEGINNING starts the stage)."""
+    atoms = model_atoms()
+    out = []
+    for i in starts:
+        u, l = atoms[i]
+        out.append(f"features.{u}.denselayer{l + 1}" if u.startswith("denseblock") else
+                   "features.norm5" if u == "head" else f"features.{u}")
+    return out
 
 
 def stage_loads(costs: Sequence[float], starts: Sequence[int]) -> List[float]:
@@ -171,6 +213,55 @@ def measure_unit_times(device, micro_batch: int, image_size: int = 224, dtype: s
     return [t / iters for t in times]
 
 
+def measure_stage_times(split_points: Sequence[str], device, micro_batch: int, image_size: int = 224,
+                        dtype: str = "fp32", iters: int = 5) -> List[float]:
+    """Forward + backward milliseconds of every pipeline stage a split produces (native engine, one hipGraph per
+    stage pass, ``micro_batch`` images) - what the balance tests and ``debug.py --measure`` report."""
+    from .densenet import DenseNetStage, stage_units
+    from .native_densenet import NativeDenseNetStage
+
+    dev = torch.device(device)
+    shape = (micro_batch, 3, image_size, image_size)
+    out = []
+    for units in stage_units(split_points):
+        if os.environ.get("DDL_SPLIT_DEBUG"):
+            print(f"[split] timing stage {units}", flush=True)
+        st = NativeDenseNetStage(units, device=dev, dtype=dtype)
+        st.train()
+        if st.is_first:
+            x = _rand_images(micro_batch, image_size, dev)
+        else:
+            x = torch.randn(shape[0], shape[2], shape[3], shape[1], device=dev)                          # NHWC
+
+        def fwd_bwd(gy=None):
+            # a fresh leaf per pass: an AccumulateGrad node lives on the stream that created it, and one made
+            # by the eager pass (default stream) would pull the default stream into the capture
+            leaf = x if st.is_first else x.detach().requires_grad_(True)
+            y = st(leaf)
+            y.backward(torch.ones_like(y) if gy is None else gy)
+            return y
+
+        gy = torch.randn_like(fwd_bwd())                 # eager pass: allocator, attributes
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            fwd_bwd(gy)
+            st.assert_joined()
+        g.replay()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        out.append(e0.elapsed_time(e1) / iters)
+        for u in units:
+            shape = DenseNetStage.unit_output_shape(u, shape)
+        del g, st
+    return out
+
+
 def auto_split_points(num_stages: int, device, micro_batch: int, image_size: int = 224, dtype: str = "fp32",
                       group=None) -> Tuple[List[str], List[float]]:
     """``(split point names, per-unit costs)`` - identical on every rank of ``group`` (costs are averaged)."""
@@ -185,5 +276,5 @@ def auto_split_points(num_stages: int, device, micro_batch: int, image_size: int
         t = torch.tensor(costs, dtype=torch.float64, device=dev)
         comm.all_reduce(t, "avg", group)
         costs = [float(v) for v in t.tolist()]
-    starts = balanced_starts(costs, num_stages)
+    starts = balanced_starts(atom_costs(costs, image_size), num_stages)
     return starts_to_split_points(starts), costs

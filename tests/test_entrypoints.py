@@ -78,6 +78,14 @@ def test_pp_four_stage(tmp_path):
     assert "[GPU3] Epoch 0 | Validation QWK" in out
 
 
+def test_pp_auto_split_mid_block(tmp_path):
+    """--split-points auto: the CPU path balances on analytic costs and cuts INSIDE a dense block; three stages
+    then train / evaluate / log like the unit-boundary splits."""
+    out = _torchrun(3, "pp.py", [*SMALL, "--batch-size", "10", "--split-points", "auto"], _env(tmp_path))
+    assert "[pp] auto split for 3 stages" in out and "denselayer" in out
+    assert "[GPU2] Epoch 0 | Validation QWK" in out
+
+
 def test_hybrid_2x2_with_snapshot(tmp_path):
     out = _torchrun(4, "ddp_n_pp.py", [*SMALL, "--batch-size", "10", "--save-every", "1"], _env(tmp_path))
     assert "[GPU1] Epoch 0 | Validation QWK" in out                # last stage of dp-rank 0 (mesh[0][-1])

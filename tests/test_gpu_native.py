@@ -368,6 +368,15 @@ def test_block_transition_block(dev):
     _compare_unit(dev, ("denseblock2", "transition2", "denseblock3"), (2, 128, 8, 8), tol=3e-2, global_l2=True)
 
 
+def test_partial_dense_blocks_fwd_bwd(dev):
+    """A pipeline stage that starts and ends INSIDE dense blocks (layers 5-12 of block 2, transition 2, layers 1-8 of
+    block 3): the native units take the concatenated prefix as their input like a block takes its own."""
+    _compare_unit(dev, ("denseblock2[4:12]",), (2, 256, 8, 8))
+    _compare_unit(dev, ("denseblock1[1:6]",), (2, 96, 8, 8))            # 96 / 416 channels: not 4 * 2^k
+    _compare_unit(dev, ("denseblock3[5:24]",), (2, 416, 4, 4), tol=3e-2, global_l2=True)
+    _compare_unit(dev, ("denseblock2[4:12]", "transition2", "denseblock3[0:8]"), (2, 256, 8, 8), tol=3e-2, global_l2=True)
+
+
 def test_head_fwd_bwd(dev):
     _compare_unit(dev, ("denseblock4", "head"), (4, 512, 7, 7))
 

@@ -40,8 +40,48 @@ def test_four_stage_split_partitions_keys():
 
 
 def test_bad_split_points_rejected():
+    for bad in (["features.denseblock3.denselayer22.conv1"],     # inside a dense layer: skip tensors would cross
+                ["features.denseblock3.denselayer25"], ["features.conv0"], ["features.nonsense"]):
+        with pytest.raises(ValueError):
+            dn.stage_units(bad)
+
+
+def test_mid_block_split_is_one_tensor_and_partitions_the_model():
+    """A stage may start at any dense LAYER (the reference's fx split could not: debug.py:9 "skip connections"): the
+    concatenated prefix is the one tensor that crosses.  Stages compose to the full model, keys partition."""
+    spec = ["features.denseblock2.denselayer5", "features.denseblock3.denselayer9"]
+    units = dn.stage_units(spec)
+    assert units[0][-1] == "denseblock2[0:4]" and units[1][0] == "denseblock2[4:12]" and units[2][0] == "denseblock3[8:24]"
+    torch.manual_seed(0)
+    full = dn.densenet121(5).eval()
+    sd = full.state_dict()
+    x = torch.rand(2, 3, 64, 64)
+    h, seen = x, []
+    for i in range(3):
+        st = dn.build_stage(i, spec, 5, sd).eval()
+        assert st.output_shape(tuple(h.shape)) == tuple(st(h).shape)
+        h = st(h)
+        seen += list(st.state_dict())
+    torch.testing.assert_close(h, full(x))
+    assert sorted(seen) == sorted(sd)
+    assert dn.DenseNetStage(units[0]).output_shape((6, 3, 224, 224)) == (6, 128 + 4 * 32, 28, 28)
     with pytest.raises(ValueError):
-        dn.stage_units(["features.denseblock3.denselayer22"])    # mid-block (reference debug.py:9)
+        dn.DenseNetStage(("denseblock2[4:12]", "denseblock3"))     # not contiguous: transition2 is missing
+
+
+def test_balanced_split_points():
+    """--split-points auto: linear partition over the 63 atoms; the analytic cost model (CPU path) puts the 2-stage cut
+    inside denseblock2 (the reference's denseblock3 split leaves 73 % of the work on stage 0)."""
+    from ddl.models import split
+    costs = split.atom_costs([m * 1e-9 for m in split.analytic_unit_macs()])
+    assert len(costs) == len(dn.model_atoms()) == 63
+    for S, tol in ((2, 0.05), (3, 0.10), (4, 0.25), (8, 0.45)):
+        starts = split.balanced_starts(costs, S)
+        loads = split.stage_loads(costs, starts)
+        assert len(loads) == S and max(loads) / (sum(loads) / S) < 1 + tol, (S, loads)
+        assert len(dn.stage_units(split.starts_to_split_points(starts))) == S
+    assert split.starts_to_split_points(split.balanced_starts(costs, 2))[0].startswith("features.denseblock2.denselayer")
+    assert split.balanced_starts([1, 1, 1, 1], 2) == (2,) and split.balanced_starts([5, 1, 1, 1], 2) == (1,)
 
 
 def test_stages_compose_to_full_model():
