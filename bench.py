@@ -76,6 +76,8 @@ def main() -> None:
     ap.add_argument("--ab", default="auto", choices=["auto", "on", "off"],
                     help="grad_sync A/B + bucket-size sweep on extra steps behind the timed region (auto: when W>1)")
     ap.add_argument("--ab-steps", type=int, default=12)
+    ap.add_argument("--trace-dir", default=None, help="torch.profiler capture (Chrome trace + kernel table per rank) of "
+                                                      "4 extra steps BEHIND the timed region (ddl/utils/trace.py)")
     a = ap.parse_args()
 
     from ddl import comm
@@ -254,6 +256,15 @@ def main() -> None:
         except BaseException as e:      # noqa: BLE001 - the headline is measured; a failed extra must not lose it on THIS rank
             print(f"[rank {ctx.rank}] tuning extras failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
             grad_sync_ab = grad_sync_ab or {"error": f"{type(e).__name__}: {e}"}
+
+    if a.trace_dir:
+        from ddl.utils.trace import StepTrace
+        st = StepTrace(a.trace_dir, rank=ctx.rank, skip=1, steps=4)
+        for i in range(6):
+            st.tick()
+            run_steps(strat, 1, first=i)
+        st.tick()
+        sync()
 
     global_batch = B * dp
     value = global_batch * a.steps / dt
