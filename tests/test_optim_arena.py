@@ -97,3 +97,40 @@ def test_arena_break_before_starts_a_new_segment():
     assert [s.segment for s in a.slots] == [0, 0, 1, 1, 1, 2]
     for (n, p), s in zip(ps, a.slots):
         assert p.data_ptr() == a.flat_param[s.offset:].data_ptr()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 6, 8, 16])
+@pytest.mark.parametrize("bucket_mb", [2.0, 8.0, 32.0])
+def test_segments_split_evenly_for_every_world_size(world, bucket_mb):
+    """The reduce-scatter / all-gather buckets and the ZeRO-1 shards of the real DenseNet-121 parameter list: every
+    segment must divide by the data-parallel world size (dp.py raises otherwise), the per-rank shard ranges must
+    tile each segment exactly, and no parameter may straddle two segments.  Pure layout arithmetic - checked here
+    for the world sizes the suite never spawns (the driver's 8-GPU node, 3/6 for non-powers of two)."""
+    from ddl.models.densenet import UNIT_NAMES, DenseNetStage
+    model = DenseNetStage(UNIT_NAMES)
+    rev = reverse_named_parameters(model)
+    # phase cuts of the native engine (native_densenet.py: a new segment at the first parameter, in backward order,
+    # of the unit in front of every dense block)
+    breaks = [next(n for n, _ in rev if n.startswith(f"features.{u}.")) for u in ("transition3", "transition2", "transition1", "norm0")]
+    arena = FlatArena(rev, segment_numel=int(bucket_mb * 2 ** 20 / 4), segment_multiple=world * 64, break_before=breaks)
+    assert all(any(arena.slot_of(b).offset == s.start for s in arena.segments) for b in breaks)
+    assert arena.total_param_numel() == sum(p.numel() for p in model.parameters())
+    covered = 0
+    for seg in arena.segments:
+        n = seg.end - seg.start
+        assert n > 0 and n % world == 0 and seg.start % 64 == 0
+        covered += n
+    assert covered == arena.numel and arena.segments[0].start == 0
+    assert all(a.end == b.start for a, b in zip(arena.segments[:-1], arena.segments[1:]))
+    for i, p in enumerate(arena.params):                      # every parameter inside ONE segment
+        v = arena.param_view(i)
+        off = (v.data_ptr() - arena.flat_param.data_ptr()) // 4
+        assert any(s.start <= off and off + p.numel() <= s.end for s in arena.segments)
+    seen = torch.zeros(arena.numel, dtype=torch.int32)
+    for r in range(world):
+        opt = FusedAdam(arena, shard=(r, world))
+        ranges = opt._ranges()
+        assert len(ranges) == len(arena.segments)
+        for s, e in ranges:
+            seen[s:e] += 1
+    assert bool((seen == 1).all())                             # shards tile the arena: no gap, no overlap
