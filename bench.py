@@ -31,6 +31,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 import traceback
 
@@ -76,6 +77,8 @@ def main() -> None:
     ap.add_argument("--ab", default="auto", choices=["auto", "on", "off"],
                     help="grad_sync A/B + bucket-size sweep on extra steps behind the timed region (auto: when W>1)")
     ap.add_argument("--ab-steps", type=int, default=12)
+    ap.add_argument("--extras-timeout", type=float, default=150.0,
+                    help="seconds the tuning extras behind the timed region may take before the headline is printed without them")
     ap.add_argument("--trace-dir", default=None, help="torch.profiler capture (Chrome trace + kernel table per rank) of "
                                                       "4 extra steps BEHIND the timed region (ddl/utils/trace.py)")
     a = ap.parse_args()
@@ -227,36 +230,6 @@ def main() -> None:
         profile["profile_steps"] = n_prof
         profile["reduced_over_ranks"] = "max"
 
-    # ---- tuning data behind the timed region (multi-rank runs; `--ab on` to rehearse with one rank) ----------
-    ab = a.ab == "on" or (a.ab == "auto" and world > 1)
-    engine = getattr(strat, "dp", None)
-    grad_sync_ab, bucket_sweep = None, None
-    if ab and engine is not None and not engine.single and not a.zero1:
-        try:
-            grad_sync_ab = {}
-            chosen = engine.grad_sync
-            for mode in ("rs_ag", "allreduce"):
-                engine.set_grad_sync(mode)
-                run_steps(strat, 3)
-                t, _ = timed(strat, a.ab_steps)
-                grad_sync_ab[mode] = round(max_over_ranks(t) / a.ab_steps * 1e3, 3)
-            engine.set_grad_sync(chosen)
-            if a.mode == "ddp":
-                bucket_sweep = {str(a.bucket_mb): round(step_ms, 3)}
-                for mb in (2.0, 32.0):
-                    if mb == a.bucket_mb:
-                        continue
-                    s2 = make_strategy(mb)
-                    s2.model.train()
-                    s2.profiler.set_enabled(False)
-                    run_steps(s2, PRIME + 3)
-                    t, _ = timed(s2, a.ab_steps)
-                    bucket_sweep[str(mb)] = round(max_over_ranks(t) / a.ab_steps * 1e3, 3)
-                    del s2
-        except BaseException as e:      # noqa: BLE001 - the headline is measured; a failed extra must not lose it on THIS rank
-            print(f"[rank {ctx.rank}] tuning extras failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
-            grad_sync_ab = grad_sync_ab or {"error": f"{type(e).__name__}: {e}"}
-
     if a.trace_dir:
         from ddl.utils.trace import StepTrace
         st = StepTrace(a.trace_dir, rank=ctx.rank, skip=1, steps=4)
@@ -266,6 +239,7 @@ def main() -> None:
         st.tick()
         sync()
 
+    engine = getattr(strat, "dp", None)
     global_batch = B * dp
     value = global_batch * a.steps / dt
     base_key = "single" if (a.mode == "ddp" and world == 1) else a.mode
@@ -311,6 +285,54 @@ def main() -> None:
                              split_points=list(getattr(strat, "split_points", split)))
     if profile is not None:
         out["profile"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in profile.items()}
+
+    def emit() -> None:
+        if ctx.rank == 0:
+            print(json.dumps(out), flush=True)
+
+    # The headline is measured.  Everything behind this point is tuning data (multi-rank runs; `--ab on` to rehearse
+    # with one rank): a hang or crash in it - a collective that never completes on a first multi-GPU run - must not
+    # lose the number, so a watchdog prints the JSON without the extras and leaves.
+    def bail() -> None:
+        out["extras"] = f"abandoned after {a.extras_timeout} s (watchdog)"
+        print(f"[rank {ctx.rank}] bench.py: tuning extras did not finish in {a.extras_timeout} s - reporting the "
+              f"headline without them", file=sys.stderr, flush=True)
+        emit()
+        sys.stdout.flush()
+        os._exit(0)
+
+    watchdog = threading.Timer(a.extras_timeout, bail)
+    watchdog.daemon = True
+    watchdog.start()
+    ab = a.ab == "on" or (a.ab == "auto" and world > 1)
+    grad_sync_ab, bucket_sweep = None, None
+    if ab and engine is not None and not engine.single and not a.zero1:
+        try:
+            grad_sync_ab = {}
+            chosen = engine.grad_sync
+            for mode in ("rs_ag", "allreduce"):
+                engine.set_grad_sync(mode)
+                run_steps(strat, 3)
+                t, _ = timed(strat, a.ab_steps)
+                grad_sync_ab[mode] = round(max_over_ranks(t) / a.ab_steps * 1e3, 3)
+            engine.set_grad_sync(chosen)
+            if a.mode == "ddp":
+                bucket_sweep = {str(a.bucket_mb): round(step_ms, 3)}
+                for mb in (2.0, 32.0):
+                    if mb == a.bucket_mb:
+                        continue
+                    s2 = make_strategy(mb)
+                    s2.model.train()
+                    s2.profiler.set_enabled(False)
+                    run_steps(s2, PRIME + 3)
+                    t, _ = timed(s2, a.ab_steps)
+                    bucket_sweep[str(mb)] = round(max_over_ranks(t) / a.ab_steps * 1e3, 3)
+                    del s2
+        except BaseException as e:      # noqa: BLE001 - the headline is measured; a failed extra must not lose it on THIS rank
+            print(f"[rank {ctx.rank}] tuning extras failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            grad_sync_ab = grad_sync_ab or {"error": f"{type(e).__name__}: {e}"}
+
+    watchdog.cancel()
     if grad_sync_ab is not None:
         out["grad_sync_ab"] = grad_sync_ab          # ms/step of the same captured step with either collective form
     if bucket_sweep is not None:
@@ -318,8 +340,11 @@ def main() -> None:
     if host_bound and ctx.rank == 0:
         print(f"WARNING: host-bound run - issuing a step took {host_ms:.2f} ms of the {step_ms:.2f} ms step "
               f"(> 80 %); the GPUs wait for the host", file=sys.stderr, flush=True)
-    if ctx.rank == 0:
-        print(json.dumps(out), flush=True)
+    emit()
+    # the number is out: a teardown that cannot complete (a peer that left early) must not turn into a time-out
+    closer = threading.Timer(30.0, lambda: os._exit(0))
+    closer.daemon = True
+    closer.start()
     sync()
     comm.destroy()
 

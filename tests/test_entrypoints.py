@@ -133,6 +133,25 @@ def test_bench_json_contract_cpu(tmp_path):
     assert rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2"
     assert rec["value"] == pytest.approx(4 * 1 / (rec["ms_per_step"] / 1e3), rel=1e-3)
     assert "profile" in rec and rec["profile"]["profile_steps"] == 1 and rec["profile"]["step_ms_per_step"] > 0
+    # multi-rank runs return the tuning data in the same line: both collective forms and the bucket sweep
+    assert set(rec["grad_sync_ab"]) == {"rs_ag", "allreduce"} and set(rec["bucket_mb_sweep"]) == {"8.0", "2.0", "32.0"}
+    assert "extras" not in rec
+
+
+def test_bench_watchdog_keeps_the_headline_when_the_extras_hang(tmp_path):
+    """The A/B extras run behind the timed region; if they cannot finish (here: a 0.2 s budget) every rank still
+    leaves with status 0 and rank 0 prints the ONE JSON line, marked as without extras."""
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), "bench.py", "--gpus", "2",
+                        "--steps", "1", "--warmup", "0", "--batch-per-gpu", "2", "--extras-timeout", "0.2"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and "abandoned" in rec["extras"] and "grad_sync_ab" not in rec
 
 
 def test_rank_failure_aborts_job_and_resume_latest_recovers(tmp_path):
