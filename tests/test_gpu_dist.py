@@ -8,7 +8,7 @@ import sys
 import pytest
 import torch
 
-from dist_utils import ROOT, free_port, run_distributed
+from dist_utils import ROOT, free_port, rank_device, run_distributed
 
 pytestmark = pytest.mark.gpu
 
@@ -19,7 +19,7 @@ def _ddp_worker(rank, world, zero1):
     from ddl.models import create_stage
     from ddl.optim import FusedAdam
     from ddl.parallel.dp import DataParallelEngine
-    dev = torch.device("cuda", 0)
+    dev = rank_device(rank)
     torch.cuda.set_device(dev)
     torch.manual_seed(10 + rank)                       # ranks start different: broadcast must align them
     units = ("denseblock4", "head")
@@ -74,7 +74,7 @@ def _phased_graph_worker(rank, world):
     from ddl import comm
     from ddl.config import TrainConfig
     from ddl.trainer import DDPStrategy
-    dev = torch.device("cuda", 0)
+    dev = rank_device(rank)
     torch.cuda.set_device(dev)
     ctx = comm.CommContext(rank, world, 0, dev, "gloo")
     finals = []
@@ -115,7 +115,7 @@ def _pp_worker(rank, world, schedule, graph):
     from ddl.models import create_stage
     from ddl.models.densenet import DenseNetStage
     from ddl.parallel.pp import SCHEDULES, PipelineStage
-    dev = torch.device("cuda", 0)
+    dev = rank_device(rank)
     torch.cuda.set_device(dev)
     units = [("denseblock3", "transition3"), ("denseblock4", "head")]
     torch.manual_seed(0)                                # same seed everywhere: every rank can rebuild both stages
@@ -170,7 +170,7 @@ def _hybrid_overlap_worker(rank, world):
     from ddl import comm
     from ddl.config import TrainConfig
     from ddl.trainer import build_strategy
-    dev = torch.device("cuda", 0)
+    dev = rank_device(rank)
     torch.cuda.set_device(dev)
     ctx = comm.CommContext(rank, world, 0, dev, "gloo")
     finals = []
@@ -253,6 +253,35 @@ def test_auto_split_balances_measured_stage_times(S, tol):
         ref = split.measure_stage_times(["features.denseblock3.denselayer1"], dev, 30)
         print(f"reference split: stage ms {[round(t, 2) for t in ref]}")
         assert max(times) < max(ref)                                   # the balanced pipeline's slowest stage is faster
+
+
+# ---- the same workers over RCCL between distinct GPUs: run wherever the suite finds >= 2 GPUs (the one-GPU test
+# box skips them).  First real exercise of csrc/reducer.cpp with W > 1 and of the native P2P engine (csrc/p2p.cpp).
+needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL between distinct devices")
+
+
+@needs_two_gpus
+@pytest.mark.parametrize("zero1", [False, True])
+def test_native_ddp_two_gpus_rccl(zero1):
+    run_distributed(_ddp_worker, 2, zero1, timeout=300, backend="nccl")
+
+
+@needs_two_gpus
+def test_phased_graph_ddp_two_gpus_rccl():
+    run_distributed(_phased_graph_worker, 2, timeout=300, backend="nccl")
+
+
+@needs_two_gpus
+@pytest.mark.parametrize("schedule,graph", [("1f1b", False), ("1f1b", True), ("gpipe", True)])
+def test_native_pipeline_two_gpus_rccl(schedule, graph):
+    run_distributed(_pp_worker, 2, schedule, graph, timeout=300, backend="nccl")
+
+
+@needs_two_gpus
+def test_hybrid_overlap_four_gpus_rccl():
+    if torch.cuda.device_count() < 4:
+        pytest.skip("needs four GPUs (2 x 2 mesh)")
+    run_distributed(_hybrid_overlap_worker, 4, timeout=400, backend="nccl")
 
 
 def _torchrun(n, script, args, tmp_path):
