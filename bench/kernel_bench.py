@@ -19,6 +19,8 @@ ap.add_argument("--bf16", action="store_true", help="bf16 MFMA inputs for the co
 ap.add_argument("--min-rows", type=int, default=64, help="wgrad: minimum pixel rows per workgroup")
 ap.add_argument("--sub", type=int, default=0, help="wgrad 1x1: force the sub-tile count (1, 3, 4) of the channel tiles")
 ap.add_argument("--defer", action="store_true", help="wgrad: queue the slab reductions (timed: the slab kernels alone)")
+ap.add_argument("--probe", action="store_true", help="phase timestamps of the first / last workgroup (needs a "
+                                                   "DDL_BUILD_DEFINES=-DDDL_PHASE_PROBE build of the extension)")
 ap.add_argument("--sweep", action="store_true", help="time every conv_gemm tile config per case")
 ap.add_argument("--cfg", type=int, default=-1, help="explicit conv_gemm tile config id (csrc/conv_gemm.hip)")
 a = ap.parse_args()
@@ -137,10 +139,39 @@ for (blk, H, Cl, Cf) in [("b1", 56, 64, 256), ("b1", 56, 96, 256), ("b1", 56, 22
         ext.conv_wgrad(g2, h, k[0], k[1], k[2], buf[:, :Cl], sc, sh, True, M, H, H, 1, gw1, a.min_rows, force_sub=a.sub, **WQ)
     cases.append((f"{blk}_wgrad1x1_C{Cl}", 2.0 * M * Cl * 128, f5x))
 
+PHASES = ["entry", "loads issued + tables", "first slab in LDS", "K loop", "K-split combine", "epilogue stores issued",
+          "statistics", "vmcnt(0) + barrier", "end"]
+
+
+def probe(name, fn):
+    dbg = torch.zeros(32, dtype=torch.int64, device=dev)
+    ext.set_phase_probe(dbg)
+    fn()
+    torch.cuda.synchronize()
+    ext.set_phase_probe(None)
+    t = dbg.cpu().tolist()
+    for label, off in (("first WG", 0), ("last WG", 16)):
+        v = t[off:off + 9]
+        if v[0] == 0:
+            continue
+        parts, prev = [], v[0]
+        for i in range(1, 9):
+            if v[i]:
+                parts.append(f"{PHASES[i]} +{(v[i] - prev) / 100:.2f}")
+                prev = v[i]
+        print(f"    {label}: " + " | ".join(parts) + f" | total {(prev - v[0]) / 100:.2f} us"
+              + (f" | starts {(t[16] - t[0]) / 100:+.2f} us after the first WG" if off == 16 else ""), flush=True)
+
+
 for name, flops, fn in cases:
     if WQ:
         WQ["queue"].flush()
     if a.only and a.only not in name:
+        continue
+    if a.probe:
+        us = timeit(fn)
+        print(f"{name:28s} {us:7.1f} us", flush=True)
+        probe(name, fn)
         continue
     if a.sweep:
         if "wgrad" in name:

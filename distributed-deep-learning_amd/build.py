@@ -64,6 +64,9 @@ def build(force: bool = False, verbose: bool = True) -> Path:
                  "-DTORCH_API_INCLUDE_EXTENSION_H", "-D_GLIBCXX_USE_CXX11_ABI=1",
                  "-Wno-unused-result", "-Wno-deprecated-declarations",
                  f"-I{CSRC}", f"-I{sysconfig.get_paths()['include']}"] + [f"-I{i}" for i in incs]
+    extra = os.environ.get("DDL_BUILD_DEFINES", "").split()      # e.g. -DDDL_PHASE_PROBE (bench/phase_probe.py)
+    hip_flags += extra
+    cpp_flags += extra
     jobs = []
     for src in sorted(CSRC.glob("*.hip")):
         jobs.append((src, hip_flags))

@@ -70,6 +70,18 @@ float* fvec(const at::Tensor& t, int64_t n, const char* name) {
   return t.data_ptr<float>();
 }
 
+#ifdef DDL_PHASE_PROBE
+long long* g_phase_probe = nullptr;      // bench/phase_probe.py: [2][16] int64 device buffer, or null
+void set_phase_probe(const OptT& t) {
+  if (!t.has_value()) { g_phase_probe = nullptr; return; }
+  TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kLong && t->is_contiguous() && t->numel() >= 32, "probe: int64[32]");
+  g_phase_probe = reinterpret_cast<long long*>(t->data_ptr<int64_t>());
+}
+#define DDL_SET_PROBE(p) (p).dbg = g_phase_probe
+#else
+#define DDL_SET_PROBE(p) do {} while (0)
+#endif
+
 // fused BN-backward coefficients (FusedK): accumulators + the BN's forward statistics
 ddl::FusedK make_fk(const OptT& acc, const OptT& mean, const OptT& rstd, const OptT& scale, const OptT& dgamma,
                     const OptT& dbeta, double count, int64_t n) {
@@ -180,6 +192,7 @@ at::Tensor conv_gemm(const at::Tensor& x0, const OptT& x1, const OptT& s0, const
     p.tail.k1 = fvec(*tail_k1, N, "tail_k1"); p.tail.k2 = fvec(*tail_k2, N, "tail_k2");
     if (tail_mode == 0) { TORCH_CHECK(tail_k0.has_value(), "tail mode 0 needs k0"); p.tail.k0 = fvec(*tail_k0, N, "tail_k0"); }
   }
+  DDL_SET_PROBE(p);
   ddl::launch_conv_gemm(p, (int)force_bm, cur_stream());
   return stats;
 }
@@ -247,6 +260,7 @@ void conv_fwd_fused(const at::Tensor& x, const at::Tensor& acc_in, int64_t new0,
   const int64_t wb = ((N - 1) * (int64_t)p.ldb + taps * C) * 4, ob = ((M - 1) * (int64_t)p.ldo + N) * 4;
   TORCH_CHECK(wb < (1LL << 31) && ob < (1LL << 31), "conv_fwd_fused: views must span < 2 GiB");
   p.wbytes = (unsigned)wb; p.obytes = (unsigned)ob;
+  DDL_SET_PROBE(p);
   ddl::launch_conv_gemm(p, (int)force_bm, cur_stream());
 }
 
@@ -516,6 +530,9 @@ void register_conv_ops(pybind11::module_& m) {
         pybind11::arg("tail_scale") = c10::nullopt, pybind11::arg("tail_dgamma") = c10::nullopt,
         pybind11::arg("tail_dbeta") = c10::nullopt, pybind11::arg("tail_k0") = c10::nullopt,
         pybind11::arg("tail_k1") = c10::nullopt, pybind11::arg("tail_k2") = c10::nullopt);
+#ifdef DDL_PHASE_PROBE
+  m.def("set_phase_probe", &set_phase_probe, "device buffer for the kernels' phase timestamps (probe builds only)");
+#endif
   m.def("conv_fwd_fused", &conv_fwd_fused, "forward conv with fused batch-norm statistics (accumulator in / out)");
   m.attr("STAT_REPLICAS") = pybind11::int_(ddl::kStatReplicas);
   m.def("bn_acc_finalize", &bn_acc_finalize, "accumulators -> channel mean / var / rstd");

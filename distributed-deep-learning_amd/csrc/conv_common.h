@@ -136,6 +136,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16 (&
       }
     }
   }
+  DDL_PROBE(p, 5);
   if (p.stats) {
     // per-lane column-quad sums -> red[which][row group (WM * 8)][BN] -> one sum per column
     constexpr int RG = WM * 8;
@@ -165,10 +166,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16 (&
       }
     }
   }
+  DDL_PROBE(p, 6);
   // ---- BN-backward bookkeeping by the last-arriving workgroup of this column tile (TailPrep) -----------------
   if ((KIND == 2 || KIND == 3) && p.tail.counters != nullptr) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's statistics atomics are out
     __syncthreads();
+    DDL_PROBE(p, 7);
     int* flag = reinterpret_cast<int*>(smem);
     if (tid == 0) {
       // Everything the last arriver reads from its peers - the statistics accumulators - was written with

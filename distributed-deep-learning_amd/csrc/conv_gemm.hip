@@ -74,6 +74,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
   static_assert(TM >= 1 && TN >= 1, "bad wave layout");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  DDL_PROBE(p, 0);
   // forward kind with a BN prologue: scale / shift of all C channels live in LDS ahead of the staging
   // buffers (copied from the tables, or derived from the fused-statistics accumulators)
   const bool affine = p.a.s0 != nullptr || (KIND == 0 && p.bn.acc != nullptr) || (KIND == 3 && p.fk.acc != nullptr);
@@ -317,9 +318,11 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
     Stage S;
     load_slab(0, S);
     bn_tables();
+    DDL_PROBE(p, 1);
     if (LDS_TABLES) __syncthreads();
     store_slab(0, S);
     __syncthreads();
+    DDL_PROBE(p, 2);
     for (int kt = 0; kt < KT; ++kt) {
       const int buf = NBUF == 2 ? (kt & 1) : 0;
       if (kt + 1 < KT) load_slab(kt + 1, S);      // global loads fly under this slab's MFMAs
@@ -330,15 +333,24 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
     }
   } else {
     // prefetch distance 2 (NBUF == 2): slab kt in LDS, slab kt+1 in registers, slab kt+2 being loaded.
+    // (Round 2, measured: the conditional prefetches below make the number of outstanding loads path-dependent, so
+    // the compiler drains to vmcnt(0) before the older slab is consumed and the distance is really 1.  Issuing
+    // every load unconditionally - out-of-range slabs read zeros - gives the intended vmcnt(5) / vmcnt(15) waits
+    // for distance 2 / 4, and changes NOTHING in the run time of any DenseNet shape (bench/kernel_bench.py --sweep:
+    // 19.2 / 19.6 vs 19.3 us for the block-3 1x1 forward): the phase probes show the K loop of the small-M tiles at
+    // 1.4 us per slab because the two K-split waves of a tile share one SIMD's MFMA pipe (2 x 0.43 us) plus the
+    // barrier - it is matrix-core bound per CU, not latency bound.  The simpler form stays.)
     // For the latency-bound small-M layers (a handful of workgroups per CU at most) a slab's loads
     // get two compute phases to land instead of one.
     Stage S0, S1;
     load_slab(0, S0);
     if (KT > 1) load_slab(1, S1);
     bn_tables();
+    DDL_PROBE(p, 1);
     if (LDS_TABLES) __syncthreads();
     store_slab(0, S0);
     __syncthreads();
+    DDL_PROBE(p, 2);
     for (int kt = 0; kt < KT; kt += 2) {
       if (kt + 2 < KT) load_slab(kt + 2, S0);
       compute(0);
@@ -352,6 +364,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
     }
   }
 
+  DDL_PROBE(p, 3);
   // ---- combine the K-split partial accumulators ---------------------------------------------
   if (KS > 1) {
     float* red = smem;   // [(KS-1)][WM*WN][TM*TN*16][64]
@@ -379,7 +392,9 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
     __syncthreads();
   }
 
+  DDL_PROBE(p, 4);
   conv_epilogue<BM, BN, WM, WN, NT, KIND>(p, acc, smem, m0, n0, tile_x, tid, ks, wmn);
+  DDL_PROBE(p, 8);
 }
 
 template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF, int KIND, bool BF>

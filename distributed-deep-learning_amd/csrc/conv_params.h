@@ -135,6 +135,9 @@ struct ConvGemmParams {
   int bf16;           // 1: bf16 MFMA inputs (rounded at the LDS write), fp32 accumulate
   int inv_cc;         // ceil(2^16 / (C / 32)): sub-slab index -> (tap, channel chunk) without a division
   unsigned wbytes, obytes, auxbytes;   // extents of weight / out / aux in bytes
+#ifdef DDL_PHASE_PROBE
+  long long* dbg;     // [2][16] phase timestamps (100 MHz) of the first and the last workgroup (bench/phase_probe.py)
+#endif
 };
 
 // dW[N x taps*C] += dO^T[N x M] * rows(A)[M x taps*C]   (weight gradient; split over M, slab output)

@@ -57,3 +57,15 @@ __device__ __forceinline__ void fused_k(const FK& f, int c, int replicas, double
 }
 
 }  // namespace ddl
+
+// Phase probes (-DDDL_PHASE_PROBE builds only, bench/phase_probe.py): thread 0 of the first and the last workgroup of
+// column tile 0 stamps the constant 100 MHz clock at phase boundaries of a kernel.
+#ifdef DDL_PHASE_PROBE
+#define DDL_PROBE(p, i)                                                                                        \
+  do {                                                                                                         \
+    if ((p).dbg != nullptr && threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) \
+      (p).dbg[(blockIdx.x == 0 ? 0 : 16) + (i)] = (long long)wall_clock64();                                    \
+  } while (0)
+#else
+#define DDL_PROBE(p, i) do {} while (0)
+#endif
