@@ -110,13 +110,14 @@ def main() -> None:
     else:
         split = default_split_points(max(pp_size, 1))
 
-    def make_strategy(bucket_mb: float):
+    def make_strategy(bucket_mb: float, grad_phases=None):
+        gp = a.grad_phases if grad_phases is None else grad_phases
         cfg = TrainConfig(strategy=strategy_name, batch_size=B, dtype=a.dtype,
                           bucket_mb=bucket_mb, zero1=a.zero1, hip_graph=not a.no_graph,
                           num_microbatches=n_mb, schedule=a.schedule, pp_size=pp_size,
                           split_points=split, profile=a.profile,
                           sync_buffers=a.sync_buffers, num_workers=0,
-                          **({} if a.grad_phases is None else {"grad_phases": a.grad_phases}),
+                          **({} if gp is None else {"grad_phases": gp}),
                           **({} if a.grad_sync is None else {"grad_sync": a.grad_sync}))
         return build_strategy(cfg, ctx)
 
@@ -305,7 +306,7 @@ def main() -> None:
     watchdog.daemon = True
     watchdog.start()
     ab = a.ab == "on" or (a.ab == "auto" and world > 1)
-    grad_sync_ab, bucket_sweep = None, None
+    grad_sync_ab, bucket_sweep, phase_sweep = None, None, None
     if ab and engine is not None and not engine.single and not a.zero1:
         try:
             grad_sync_ab = {}
@@ -328,6 +329,19 @@ def main() -> None:
                     t, _ = timed(s2, a.ab_steps)
                     bucket_sweep[str(mb)] = round(max_over_ranks(t) / a.ab_steps * 1e3, 3)
                     del s2
+                if not a.no_graph and dev.type == "cuda":
+                    # where the backward graph chain is cut (= when finished buckets can leave): the default, no cut
+                    # (every bucket behind the whole backward), one cut, a cut at every dense block
+                    phase_sweep = {"default": round(step_ms, 3)}
+                    for name, gp in (("none", ""), ("denseblock3", "denseblock3"),
+                                     ("every block", "denseblock4,denseblock3,denseblock2,denseblock1")):
+                        s2 = make_strategy(a.bucket_mb, gp)
+                        s2.model.train()
+                        s2.profiler.set_enabled(False)
+                        run_steps(s2, PRIME + 3)
+                        t, _ = timed(s2, a.ab_steps)
+                        phase_sweep[name] = round(max_over_ranks(t) / a.ab_steps * 1e3, 3)
+                        del s2
         except BaseException as e:      # noqa: BLE001 - the headline is measured; a failed extra must not lose it on THIS rank
             print(f"[rank {ctx.rank}] tuning extras failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
             grad_sync_ab = grad_sync_ab or {"error": f"{type(e).__name__}: {e}"}
@@ -337,6 +351,8 @@ def main() -> None:
         out["grad_sync_ab"] = grad_sync_ab          # ms/step of the same captured step with either collective form
     if bucket_sweep is not None:
         out["bucket_mb_sweep"] = bucket_sweep       # ms/step per bucket size (MiB)
+    if phase_sweep is not None:
+        out["grad_phase_sweep"] = phase_sweep       # ms/step per placement of the backward graph cuts
     if host_bound and ctx.rank == 0:
         print(f"WARNING: host-bound run - issuing a step took {host_ms:.2f} ms of the {step_ms:.2f} ms step "
               f"(> 80 %); the GPUs wait for the host", file=sys.stderr, flush=True)

@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv3x3_halo_kernel(const ConvGe
   const int n0 = blockIdx.y * BN;
   const int chunks = p.C >> 5;
 
-  const rsrc_t rA = make_rsrc(p.a.X0, p.a.bytes0);
+  const int mbase = m0 > halo ? m0 - halo : 0;          // first row the staged range can touch
+  const rsrc_t rA = make_rsrc_rows(p.a.X0, p.a.bytes0, mbase, p.a.ld0);
   const rsrc_t rW = make_rsrc(p.Wt, p.wbytes);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -74,7 +75,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv3x3_halo_kernel(const ConvGe
   for (int i = 0; i < PA; ++i) {
     const int r = (tid + i * NT) >> 3;
     const int m = m0 - halo + r;
-    a_off[i] = (r < R && m >= 0 && m < p.M) ? (unsigned)m * (unsigned)(p.a.ld0 * 4) + (unsigned)(16 * cq) : OOB;
+    a_off[i] = (r < R && m >= 0 && m < p.M) ? (unsigned)(m - mbase) * (unsigned)(p.a.ld0 * 4) + (unsigned)(16 * cq) : OOB;
   }
   // ---- compute roles: 9-bit tap mask of this lane's pixel in each of its row blocks ------------------
   unsigned bits[TM];
@@ -247,7 +248,8 @@ __global__ void __launch_bounds__(64 * (BM / 32) * KS) conv3x3_small_kernel(cons
   const int npairs = chunks * 9;
   const int qrow = p.C >> 2;                           // float4 per row
 
-  const rsrc_t rA = make_rsrc(p.a.X0, p.a.bytes0);
+  const int mbase = m0 > halo ? m0 - halo : 0;          // first row the staged range can touch
+  const rsrc_t rA = make_rsrc_rows(p.a.X0, p.a.bytes0, mbase, p.a.ld0);
   const rsrc_t rW = make_rsrc(p.Wt, p.wbytes);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -259,7 +261,7 @@ __global__ void __launch_bounds__(64 * (BM / 32) * KS) conv3x3_small_kernel(cons
     const int r = f / qrow, cq = f - r * qrow;
     const int m = m0 - halo + r;
     const bool ok = r < R && m >= 0 && m < p.M;
-    a_v[i] = bld4(rA, ok ? (unsigned)m * (unsigned)(p.a.ld0 * 4) + (unsigned)(16 * cq) : OOB);
+    a_v[i] = bld4(rA, ok ? (unsigned)(m - mbase) * (unsigned)(p.a.ld0 * 4) + (unsigned)(16 * cq) : OOB);
   }
   // this lane's 9-bit tap mask (its pixel is row li of row block wm)
   unsigned bits = 0;

@@ -52,9 +52,8 @@ ddl::RowSrc make_src(const at::Tensor& x0, const OptT& x1, const OptT& s0, const
   // extents for the buffer descriptors (32-bit offsets, hardware bounds check)
   const int64_t b0 = ((rows - 1) * (int64_t)r.ld0 + ch) * 4;
   const int64_t b1 = r.X1 ? ((rows - 1) * (int64_t)r.ld1 + ch) * 4 : 0;
-  TORCH_CHECK(b0 < (1LL << 31) && b1 < (1LL << 31), name, ": operand view must span < 2 GiB");
-  r.bytes0 = (unsigned)b0;
-  r.bytes1 = (unsigned)b1;
+  r.bytes0 = (long)b0;      // any size: the kernels rebase their descriptors per workgroup (device_utils.h)
+  r.bytes1 = (long)b1;
   return r;
 }
 
@@ -155,8 +154,8 @@ at::Tensor conv_gemm(const at::Tensor& x0, const OptT& x1, const OptT& s0, const
   const int64_t wb = b_kmajor ? ((C - 1) * (int64_t)p.ldb + taps * N) * 4 : ((N - 1) * (int64_t)p.ldb + taps * C) * 4;
   const int64_t ob = ((M - 1) * (int64_t)p.ldo + N) * 4;
   const int64_t xb = p.aux ? ((M - 1) * (int64_t)p.ldaux + N) * 4 : 0;
-  TORCH_CHECK(wb < (1LL << 31) && ob < (1LL << 31) && xb < (1LL << 31), "conv_gemm: views must span < 2 GiB");
-  p.wbytes = (unsigned)wb; p.obytes = (unsigned)ob; p.auxbytes = (unsigned)xb;
+  TORCH_CHECK(wb < (1LL << 31), "conv_gemm: the weight tensor must span < 2 GiB");
+  p.wbytes = (unsigned)wb; p.obytes = (long)ob; p.auxbytes = (long)xb;
   if (p.fk.acc != nullptr) { TORCH_CHECK(p.kind == 3 && C <= ddl::kMaxAffineC, "fused k: 1x1 data gradient only"); }
   if (p.kind == 3) { TORCH_CHECK(C <= ddl::kMaxAffineC, "conv_gemm: dgrad1x1 stages its coefficients for <= 1024 channels"); }
   if (p.kind == 0 && p.a.s0 != nullptr) { TORCH_CHECK(C <= ddl::kMaxAffineC, "conv_gemm: BN prologue for <= 1024 channels"); }
@@ -258,8 +257,8 @@ void conv_fwd_fused(const at::Tensor& x, const at::Tensor& acc_in, int64_t new0,
   TORCH_CHECK(taps * cch <= 320, "conv_fwd_fused: K too large for the sub-slab index arithmetic");
   p.inv_cc = (int)((65536 + cch - 1) / cch);
   const int64_t wb = ((N - 1) * (int64_t)p.ldb + taps * C) * 4, ob = ((M - 1) * (int64_t)p.ldo + N) * 4;
-  TORCH_CHECK(wb < (1LL << 31) && ob < (1LL << 31), "conv_fwd_fused: views must span < 2 GiB");
-  p.wbytes = (unsigned)wb; p.obytes = (unsigned)ob;
+  TORCH_CHECK(wb < (1LL << 31), "conv_fwd_fused: the weight tensor must span < 2 GiB");
+  p.wbytes = (unsigned)wb; p.obytes = (long)ob;
   DDL_SET_PROBE(p);
   ddl::launch_conv_gemm(p, (int)force_bm, cur_stream());
 }

@@ -91,8 +91,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16 (&
   for (int j = 0; j < TN; ++j) { st1[j] = zero4; st2[j] = zero4; }
   const int erow = lane >> 3, ecq = lane & 7;      // epilogue role: row (+8p) and column quad of the tile
   if (ks == 0) {
-    const rsrc_t rO = make_rsrc(p.out, p.obytes);
-    const rsrc_t rX = make_rsrc(EPM ? p.aux : p.out, EPM ? p.auxbytes : p.obytes);
+    const rsrc_t rO = make_rsrc_rows(p.out, p.obytes, m0, p.ldo);            // rebased at this tile's first row
+    const rsrc_t rX = make_rsrc_rows(EPM ? p.aux : p.out, EPM ? p.auxbytes : p.obytes, m0, EPM ? p.ldaux : p.ldo);
     float* T = smem + wmn * (32 * TLD);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -107,7 +107,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16 (&
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lh) * TLD + li] = acc[i][j][r];
-        const unsigned row0 = (unsigned)(m0 + (wm * TM + i) * 32 + erow);
+        const unsigned row0 = (unsigned)((wm * TM + i) * 32 + erow);           // relative to m0
         const unsigned obase = colok ? (row0 * (unsigned)p.ldo + (unsigned)col) * 4u : OOB;
         const unsigned xbase = colok ? (row0 * (unsigned)p.ldaux + (unsigned)col) * 4u : OOB;
         f32x4 axv[4], oldv[4], v[4];

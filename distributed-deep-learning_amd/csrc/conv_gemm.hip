@@ -109,8 +109,11 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
   const int NS = p.taps * cchunks;         // sub-slabs in all
   const int KT = (NS + KS - 1) / KS;
 
-  const rsrc_t rA0 = make_rsrc(p.a.X0, p.a.bytes0);
-  const rsrc_t rA1 = make_rsrc(TWO ? p.a.X1 : p.a.X0, TWO ? p.a.bytes1 : p.a.bytes0);
+  // source descriptors start at the first row this tile can touch (its rows, minus the 3x3 halo)
+  const int halo_rows = p.taps > 1 ? p.W + 1 : 0;
+  const int mbase = m0 > halo_rows ? m0 - halo_rows : 0;
+  const rsrc_t rA0 = make_rsrc_rows(p.a.X0, p.a.bytes0, mbase, p.a.ld0);
+  const rsrc_t rA1 = make_rsrc_rows(TWO ? p.a.X1 : p.a.X0, TWO ? p.a.bytes1 : p.a.bytes0, mbase, TWO ? p.a.ld1 : p.a.ld0);
   const rsrc_t rW = make_rsrc(p.Wt, p.wbytes);
 
   // ---- per-thread bookkeeping -----------------------------------------------------------------
@@ -122,8 +125,8 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     const int m = m0 + a_row0 + i * RSTEP;
-    a_off0[i] = (unsigned)m * (unsigned)(p.a.ld0 * 4);
-    if (TWO) a_off1[i] = (unsigned)m * (unsigned)(p.a.ld1 * 4);
+    a_off0[i] = (unsigned)(m - mbase) * (unsigned)(p.a.ld0 * 4);
+    if (TWO) a_off1[i] = (unsigned)(m - mbase) * (unsigned)(p.a.ld1 * 4);
     unsigned bits = 0;
     if (m < p.M) {
       bits = 1;

@@ -20,8 +20,8 @@ struct RowSrc {
   int ld0;
   int ld1;
   int relu;
-  unsigned bytes0;    // extent of the X0 / X1 views in bytes (buffer-descriptor bounds, < 2 GiB)
-  unsigned bytes1;
+  long bytes0;        // extent of the X0 / X1 views in bytes (64-bit: kernels rebase their descriptors per workgroup,
+  long bytes1;        //   device_utils.h make_rsrc_rows)
 };
 
 // Fused batch-norm statistics (forward, training).  The producing conv adds its per-tile column sums
@@ -134,7 +134,8 @@ struct ConvGemmParams {
   int kind;           // 0 FWD, 1 TDGRAD, 2 DGRAD3, 3 DGRAD1 (see conv_gemm.hip)
   int bf16;           // 1: bf16 MFMA inputs (rounded at the LDS write), fp32 accumulate
   int inv_cc;         // ceil(2^16 / (C / 32)): sub-slab index -> (tap, channel chunk) without a division
-  unsigned wbytes, obytes, auxbytes;   // extents of weight / out / aux in bytes
+  unsigned wbytes;    // extent of the weight tensor in bytes
+  long obytes, auxbytes;               // extents of out / aux in bytes (rebased per workgroup like the sources)
 #ifdef DDL_PHASE_PROBE
   long long* dbg;     // [2][16] phase timestamps (100 MHz) of the first and the last workgroup (bench/phase_probe.py)
 #endif

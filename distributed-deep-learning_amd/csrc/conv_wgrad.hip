@@ -53,14 +53,16 @@ __device__ __forceinline__ ColAffine col_affine(const RowSrc& a, int c, bool col
 struct SrcDesc {
   rsrc_t r0, r1;
   unsigned ld0, ld1;
+  int row0;           // the descriptors start at this row (the workgroup's pixel chunk, minus a halo): see make_rsrc_rows
   bool two;
 };
 
-__device__ __forceinline__ SrcDesc src_desc(const RowSrc& a) {
+__device__ __forceinline__ SrcDesc src_desc(const RowSrc& a, int row0) {
   SrcDesc d;
   d.two = a.X1 != nullptr;
-  d.r0 = make_rsrc(a.X0, a.bytes0);
-  d.r1 = make_rsrc(d.two ? a.X1 : a.X0, d.two ? a.bytes1 : a.bytes0);
+  d.row0 = row0 > 0 ? row0 : 0;
+  d.r0 = make_rsrc_rows(a.X0, a.bytes0, d.row0, a.ld0);
+  d.r1 = make_rsrc_rows(d.two ? a.X1 : a.X0, d.two ? a.bytes1 : a.bytes0, d.row0, d.two ? a.ld1 : a.ld0);
   d.ld0 = (unsigned)(a.ld0 * 4);
   d.ld1 = (unsigned)(a.ld1 * 4);
   return d;
@@ -77,9 +79,9 @@ template <bool TWO>
 __device__ __forceinline__ RawPix pix_fetch(const SrcDesc& d, int row, int c, bool valid) {
   RawPix r;
   r.ok = valid;
-  r.v0 = bld4(d.r0, valid ? (unsigned)row * d.ld0 + (unsigned)(c * 4) : OOB);
+  r.v0 = bld4(d.r0, valid ? (unsigned)(row - d.row0) * d.ld0 + (unsigned)(c * 4) : OOB);
   r.v1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (TWO) r.v1 = bld4(d.r1, valid ? (unsigned)row * d.ld1 + (unsigned)(c * 4) : OOB);
+  if (TWO) r.v1 = bld4(d.r1, valid ? (unsigned)(row - d.row0) * d.ld1 + (unsigned)(c * 4) : OOB);
   return r;
 }
 
@@ -131,7 +133,7 @@ __device__ __forceinline__ void wgrad1x1_body(const WgradParams& p, const int bi
   int me = mb + p.rows_per_wg;
   if (me > p.M) me = p.M;
   const int steps = (me - mb + RK - 1) / RK;
-  const SrcDesc dd = src_desc(p.d), da = src_desc(p.a);
+  const SrcDesc dd = src_desc(p.d, mb), da = src_desc(p.a, mb);
 
   const int q = 4 * (tid & 31);          // dO tile: this thread's channel quad, rows (tid >> 5) + 8 i
   const int ar = tid >> 3;               // activation tile: this thread's row, channel quads 4 (tid & 7) + 32 j
@@ -284,7 +286,7 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradParams& p, const int bi
   int me = mb + p.rows_per_wg;
   if (me > p.M) me = p.M;
   const int steps = (me - mb + RK - 1) / RK;
-  const SrcDesc dd = src_desc(p.d), da = src_desc(p.a);
+  const SrcDesc dd = src_desc(p.d, mb), da = src_desc(p.a, mb - p.W - 1);      // activation rows reach one image row back
 
   const ColAffine kd = col_affine(p.d, 4 * (tid & 7), true);
   const ColAffine ka = col_affine(p.a, cbase + 4 * (tid & 31), cbase + 4 * (tid & 31) < p.C);
@@ -404,11 +406,11 @@ __global__ void __launch_bounds__(256, 2) wgrad_group_kernel(const WgradGroupPar
   p.fk.inv_count = 0.0; p.fk.dgamma = nullptr; p.fk.dbeta = nullptr;
   p.d.X0 = en.d0; p.d.X1 = en.d1; p.d.s0 = en.ds0; p.d.s1 = en.ds1; p.d.s2 = en.ds2;
   p.d.ld0 = g.ld_d0; p.d.ld1 = g.ld_d1; p.d.relu = 0;
-  p.d.bytes0 = (unsigned)((((long)g.M - 1) * g.ld_d0 + dch) * 4);
-  p.d.bytes1 = (unsigned)((((long)g.M - 1) * g.ld_d1 + dch) * 4);
+  p.d.bytes0 = (((long)g.M - 1) * g.ld_d0 + dch) * 4;
+  p.d.bytes1 = (((long)g.M - 1) * g.ld_d1 + dch) * 4;
   p.a.X0 = en.a0; p.a.X1 = nullptr; p.a.s0 = en.as0; p.a.s1 = nullptr; p.a.s2 = en.as2;
   p.a.ld0 = g.ld_a0; p.a.ld1 = 0; p.a.relu = g.a_relu;
-  p.a.bytes0 = (unsigned)((((long)g.M - 1) * g.ld_a0 + ach) * 4);
+  p.a.bytes0 = (((long)g.M - 1) * g.ld_a0 + ach) * 4;
   p.a.bytes1 = 0;
   p.M = g.M; p.C = en.C; p.N = g.N; p.H = g.H; p.W = g.W; p.taps = TAPS;
   p.rows_per_wg = g.rows_per_wg; p.slabs = en.slabs; p.S = g.S; p.sub = 4; p.ctiles = en.ctiles;

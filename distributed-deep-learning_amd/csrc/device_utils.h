@@ -22,10 +22,21 @@ using rsrc_t = __amdgpu_buffer_rsrc_t;
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
-constexpr unsigned OOB = 0x80000000u;     // beyond any descriptor: views are < 2 GiB (checked on the host)
+constexpr unsigned OOB = 0x80000000u;     // beyond any descriptor: extents are clamped to 2^31 - 1 (make_rsrc_rows)
 
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+// Descriptor over the rows >= row0 of a row-major fp32 view of `bytes` bytes.  A 32-bit offset reaches 2 GiB, so
+// tensors beyond that (batches of more than ~650 images at 56x56x256) are addressed by REBASING the descriptor per
+// workgroup: row0 comes from blockIdx (scalar arithmetic, the descriptor stays in SGPRs), offsets are relative to
+// it, and the window one workgroup touches (its row tile plus a 3x3 halo) is a few megabytes.  The extent is
+// clamped below the OOB sentinel, so "offset = OOB" still selects nothing.
+__device__ __forceinline__ rsrc_t make_rsrc_rows(const float* p, long bytes, long row0, int ld) {
+  const long off = row0 * (long)ld * 4;
+  long rem = bytes - off;
+  rem = rem < 0 ? 0 : (rem > 0x7fffffffL ? 0x7fffffffL : rem);
+  return make_rsrc(reinterpret_cast<const char*>(p) + off, (unsigned)rem);
 }
 __device__ __forceinline__ f32x4 bld4(rsrc_t r, unsigned off) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));

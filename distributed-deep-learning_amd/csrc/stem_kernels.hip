@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) stem_conv_fwd_kernel(const float* __restr
                                                             const float* __restrict__ wp,
                                                             float* __restrict__ y0, float* __restrict__ stats,
                                                             int M, int H, int W, int H0, int W0,
-                                                            unsigned xp_bytes) {
+                                                            long xp_bytes) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                       // [2][FBM][FLD]
   float* Bs = smem + 2 * FBM * FLD;       // [2][NC0][FLD]
@@ -80,11 +80,12 @@ __global__ void __launch_bounds__(256) stem_conv_fwd_kernel(const float* __restr
   const long m0 = (long)tile_x * FBM;
   const int aq = tid & 7, a_row0 = tid >> 3;
   // buffer addressing (device_utils.h): invalid rows / padding pixels select the OOB offset
-  const rsrc_t rX = make_rsrc(xp, xp_bytes);
+  const int HW0 = H0 * W0;
+  const int bfirst = (int)(m0 / HW0);     // descriptor rebased at the first image of this tile (make_rsrc_rows)
+  const rsrc_t rX = make_rsrc_rows(xp, xp_bytes, (long)bfirst * H * W, 4);
   unsigned a_base[4];
   int a_iy0[4];
   bool a_ok[4];
-  const int HW0 = H0 * W0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = (int)m0 + a_row0 + 32 * i;
@@ -93,7 +94,7 @@ __global__ void __launch_bounds__(256) stem_conv_fwd_kernel(const float* __restr
     const int oy = rem / W0, ox = rem - oy * W0;
     const int ix = 2 * ox - 3 + aq;
     a_iy0[i] = 2 * oy - 3;
-    a_base[i] = (unsigned)((b * H + a_iy0[i]) * W + ix) * 16u;      // byte offset of filter row 0 (may wrap: unused then)
+    a_base[i] = (unsigned)(((b - bfirst) * H + a_iy0[i]) * W + ix) * 16u;      // byte offset of filter row 0 (may wrap: unused then)
     a_ok[i] = m < M && ix >= 0 && ix < W;
   }
   const unsigned row_bytes = (unsigned)W * 16u;
@@ -317,9 +318,12 @@ __global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict
   const int steps = (seg_e - seg_b + 1) / 2;
   const int segs_per_img = H0 * XS;
 
-  const unsigned y_bytes = (unsigned)(nseg / XS) * (unsigned)W0 * NC0 * 4u;       // B*H0*W0*64 floats
-  const rsrc_t rG = make_rsrc(g0, y_bytes), rY = make_rsrc(y0, y_bytes);
-  const rsrc_t rX = make_rsrc(xp, (unsigned)(nseg / segs_per_img) * (unsigned)(H * W) * 16u);
+  // descriptors rebased at the first image of this workgroup's chunk (conv0's output passes 2 GiB at ~650 images)
+  const int b0 = seg_b / segs_per_img;
+  const long nimg = nseg / segs_per_img;
+  const long y_bytes = nimg * H0 * W0 * NC0 * 4L;                                  // B*H0*W0*64 floats
+  const rsrc_t rG = make_rsrc_rows(g0, y_bytes, (long)b0 * H0 * W0, NC0), rY = make_rsrc_rows(y0, y_bytes, (long)b0 * H0 * W0, NC0);
+  const rsrc_t rX = make_rsrc_rows(xp, nimg * H * W * 16L, (long)b0 * H * W, 4);
   const int dq = 4 * (tid & 15);
   const f32x4 c0 = ld4(k0 + dq), c1 = ld4(k1 + dq), c2 = ld4(k2 + dq);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -337,7 +341,7 @@ __global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict
         const int oy = rem / XS, xs = rem - oy * XS;
         const int ox = xs * SEG + (r & 15);
         d_ok[i] = seg < seg_e && ox < W0;
-        const unsigned off = d_ok[i] ? (unsigned)(((b * H0 + oy) * W0 + ox) * NC0 + dq) * 4u : OOB;
+        const unsigned off = d_ok[i] ? (unsigned)((((b - b0) * H0 + oy) * W0 + ox) * NC0 + dq) * 4u : OOB;
         d_g[i] = bld4(rG, off);
         d_y[i] = bld4(rY, off);
       }
@@ -354,7 +358,7 @@ __global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict
         const int oy = rem / XS, xs = rem - oy * XS;
         const int iy = 2 * oy + ky - 3, ix = 2 * xs * SEG - 3 + j;
         const bool ok = f < 7 * 2 * 40 && seg < seg_e && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        r_reg[i] = bld4(rX, ok ? (unsigned)((b * H + iy) * W + ix) * 16u : OOB);
+        r_reg[i] = bld4(rX, ok ? (unsigned)(((b - b0) * H + iy) * W + ix) * 16u : OOB);
       }
     }
   };
@@ -524,7 +528,7 @@ void launch_stem_conv_fwd(const float* xp, const float* wp, float* y0, float* st
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
-  const unsigned xp_bytes = (unsigned)((M0 / ((long)H0 * W0)) * H * W * 16);      // < 2 GiB: checked by the binding
+  const long xp_bytes = (M0 / ((long)H0 * W0)) * H * W * 16;
   hipLaunchKernelGGL(stem_conv_fwd_kernel, dim3(stem_conv_grid(M0)), dim3(256), lds, s, xp, wp, y0, stats,
                      (int)M0, H, W, H0, W0, xp_bytes);
 }
