@@ -59,5 +59,30 @@ for (M, K, N, Cf) in [(1000, 128, 320, 512), (23520, 128, 320, 512)]:
                       None, None, None, 1, 0 if cfg < 0 else 1000 + cfg)
         torch.cuda.synchronize()
         bad += report(0, cfg, out, ref0, f"M={M}")
+# ---- kind 2: 3x3 data gradient (two sources, k-major flipped taps, mask) on 5 x 28 x 28 and 30 x 14 x 14 ----
+import torch.nn.functional as F  # noqa: E402
+from ddl.models.native_densenet import NativeDenseNetStage  # noqa: E402
+for (Bn, Hh) in [(5, 28), (30, 14)]:
+    Mm = Bn * Hh * Hh
+    hh = rnd(Mm, 128, seed=21)
+    sc2, sh2 = rnd(128, seed=22).abs() + 0.5, rnd(128, seed=23)
+    w3 = rnd(32, 128, 3, 3, seed=24, scale=0.05)
+    wn = NativeDenseNetStage._to_native(w3)
+    dbuf, xbuf = rnd(Mm, 256, seed=25), rnd(Mm, 256, seed=26)
+    d, x = dbuf[:, 64:96], xbuf[:, 64:96]
+    q, pp = rnd(32, seed=27, scale=0.1), rnd(32, seed=28, scale=0.1)
+    ones = torch.ones(32, device=dev)
+    dy64 = (d.double() + q.double() * x.double() + pp.double()).view(Bn, Hh, Hh, 32).permute(0, 3, 1, 2)
+    gref = F.conv_transpose2d(dy64, w3.double(), padding=1).permute(0, 2, 3, 1).reshape(Mm, 128)
+    pre = hh.double() * sc2.double() + sh2.double()
+    gref = torch.where(pre > 0, gref, torch.zeros_like(gref))
+    sure = (pre.abs() > 1e-5).double()
+    for cfg in [-1] + cfgs:
+        g2o = torch.full((Mm, 128), float("nan"), device=dev)
+        print(f"  launching kind 2 M={Mm} cfg {cfg}", flush=True)
+        ext.conv_gemm(d, x, ones, q, pp, False, Mm, Hh, Hh, 9, True, wn, True, g2o, True, False, hh, sc2, sh2, 2,
+                      0 if cfg < 0 else 1000 + cfg)
+        torch.cuda.synchronize()
+        bad += report(2, cfg, g2o.double() * sure, gref * sure, f"M={Mm}")
 print("BAD CONFIGS:", bad, flush=True)
 sys.exit(1 if bad else 0)
