@@ -29,7 +29,7 @@ namespace {
 constexpr int HALO_MAXW = 56;            // widest feature map of DenseNet-121 after the stem
 constexpr int kMaxSmallC = 128;          // small-M form: channels of the staged range (the dense layers' bottleneck width)
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool RB>
 __global__ void __launch_bounds__(64 * WM * WN) conv3x3_halo_kernel(const ConvGemmParams p) {
   constexpr int NT = 64 * WM * WN;
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
@@ -63,8 +63,9 @@ __global__ void __launch_bounds__(64 * WM * WN) conv3x3_halo_kernel(const ConvGe
   const int n0 = blockIdx.y * BN;
   const int chunks = p.C >> 5;
 
-  const int mbase = m0 > halo ? m0 - halo : 0;          // first row the staged range can touch
-  const rsrc_t rA = make_rsrc_rows(p.a.X0, p.a.bytes0, mbase, p.a.ld0);
+  constexpr bool rb = RB;                                // views beyond 2 GiB (host decision, device_utils.h)
+  const int mbase = (rb && m0 > halo) ? m0 - halo : 0;   // first row the staged range can touch
+  const rsrc_t rA = make_rsrc_rows(p.a.X0, p.a.bytes0, mbase, p.a.ld0, rb);
   const rsrc_t rW = make_rsrc(p.Wt, p.wbytes);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -203,7 +204,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv3x3_halo_kernel(const ConvGe
       __syncthreads();
     }
   }
-  conv_epilogue<BM, BN, WM, WN, NT, 0>(p, acc, smem, m0, n0, tile_x, tid, 0, wmn);
+  conv_epilogue<BM, BN, WM, WN, NT, 0, RB>(p, acc, smem, m0, n0, tile_x, tid, 0, wmn);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv3x3_halo_kernel(const ConvGe
 // channels 16h..16h+15 of output channel n) and reads its input rows from LDS at the tap's row offset.
 // No barrier until the K-split combine.  The k-steps of a pair are ordered c = 16h + s for both operands.
 // ---------------------------------------------------------------------------------------------
-template <int BM, int KS>
+template <int BM, int KS, bool RB>
 __global__ void __launch_bounds__(64 * (BM / 32) * KS) conv3x3_small_kernel(const ConvGemmParams p) {
   constexpr int WM = BM / 32, NT = 64 * WM * KS;
   constexpr int MAXW = 28;
@@ -248,8 +249,9 @@ __global__ void __launch_bounds__(64 * (BM / 32) * KS) conv3x3_small_kernel(cons
   const int npairs = chunks * 9;
   const int qrow = p.C >> 2;                           // float4 per row
 
-  const int mbase = m0 > halo ? m0 - halo : 0;          // first row the staged range can touch
-  const rsrc_t rA = make_rsrc_rows(p.a.X0, p.a.bytes0, mbase, p.a.ld0);
+  constexpr bool rb = RB;
+  const int mbase = (rb && m0 > halo) ? m0 - halo : 0;   // first row the staged range can touch
+  const rsrc_t rA = make_rsrc_rows(p.a.X0, p.a.bytes0, mbase, p.a.ld0, rb);
   const rsrc_t rW = make_rsrc(p.Wt, p.wbytes);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -349,10 +351,10 @@ __global__ void __launch_bounds__(64 * (BM / 32) * KS) conv3x3_small_kernel(cons
     }
     __syncthreads();
   }
-  conv_epilogue<BM, 32, WM, 1, NT, 0>(p, acc, smem, m0, n0, tile_x, tid, ks, wm);
+  conv_epilogue<BM, 32, WM, 1, NT, 0, RB>(p, acc, smem, m0, n0, tile_x, tid, ks, wm);
 }
 
-template <int BM, int KS>
+template <int BM, int KS, bool RB>
 void launch_small(const ConvGemmParams& p, hipStream_t s) {
   constexpr int WM = BM / 32, NT = 64 * WM * KS;
   constexpr size_t red = (size_t)(KS - 1) * WM * 16 * 64 * sizeof(float);
@@ -366,15 +368,15 @@ void launch_small(const ConvGemmParams& p, hipStream_t s) {
   if (sta > lds) lds = sta;
   static bool attr_set = false;
   if (!attr_set) {
-    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_small_kernel<BM, KS>),
+    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_small_kernel<BM, KS, RB>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     attr_set = true;
   }
   dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.N + 31) / 32));
-  hipLaunchKernelGGL((conv3x3_small_kernel<BM, KS>), grid, dim3(NT), lds, s, p);
+  hipLaunchKernelGGL((conv3x3_small_kernel<BM, KS, RB>), grid, dim3(NT), lds, s, p);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool RB>
 void launch_halo(const ConvGemmParams& p, hipStream_t s) {
   constexpr int NT = 64 * WM * WN;
   constexpr size_t b_elems = (size_t)BN * 36;
@@ -387,12 +389,12 @@ void launch_halo(const ConvGemmParams& p, hipStream_t s) {
   if (sta > lds) lds = sta;
   static bool attr_set = false;
   if (!attr_set) {
-    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, WM, WN>),
+    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<BM, BN, WM, WN, RB>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     attr_set = true;
   }
   dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.N + BN - 1) / BN));
-  hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, WM, WN>), grid, dim3(NT), lds, s, p);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, WM, WN, RB>), grid, dim3(NT), lds, s, p);
 }
 
 }  // namespace
@@ -413,8 +415,9 @@ int conv3x3_halo_bm(const ConvGemmParams& p, int force) {
 }
 
 void launch_conv3x3_halo(const ConvGemmParams& p, int bm, hipStream_t s) {
-  if (bm == 128) launch_halo<128, 32, 4, 1>(p, s);
-  else launch_small<32, 8>(p, s);
+  const bool rb = needs_rebase(p.a.bytes0, p.a.bytes1, p.obytes, p.auxbytes);   // views beyond 2 GiB: rebasing instantiation
+  if (bm == 128) { if (rb) launch_halo<128, 32, 4, 1, true>(p, s); else launch_halo<128, 32, 4, 1, false>(p, s); }
+  else { if (rb) launch_small<32, 8, true>(p, s); else launch_small<32, 8, false>(p, s); }
 }
 
 }  // namespace ddl

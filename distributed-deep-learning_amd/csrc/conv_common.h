@@ -70,7 +70,7 @@ __device__ __forceinline__ void conv_fill_tables(const ConvGemmParams& p, bool a
 // Epilogue: out (op)= acc with optional ReLU-mask / accumulate, per-column statistics into the per-tile
 // table or the fixed-point accumulators.  `ks` != 0 wave groups (K split) hold nothing and only take
 // part in the barriers.  NT = threads of the workgroup.
-template <int BM, int BN, int WM, int WN, int NT, int KIND>
+template <int BM, int BN, int WM, int WN, int NT, int KIND, bool RB>
 __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16 (&acc)[BM / (32 * WM)][BN / (32 * WN)],
                                               float* smem, int m0, int n0, int tile_x, int tid, int ks, int wmn) {
   constexpr bool EPM = KIND >= 2, EPA = KIND == 3;
@@ -91,8 +91,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16 (&
   for (int j = 0; j < TN; ++j) { st1[j] = zero4; st2[j] = zero4; }
   const int erow = lane >> 3, ecq = lane & 7;      // epilogue role: row (+8p) and column quad of the tile
   if (ks == 0) {
-    const rsrc_t rO = make_rsrc_rows(p.out, p.obytes, m0, p.ldo);            // rebased at this tile's first row
-    const rsrc_t rX = make_rsrc_rows(EPM ? p.aux : p.out, EPM ? p.auxbytes : p.obytes, m0, EPM ? p.ldaux : p.ldo);
+    // RB (views beyond 2 GiB): descriptors rebased at this tile's first row, offsets relative to it
+    constexpr bool rb = RB;
+    const int mrel = rb ? 0 : m0;                                            // row offset that stays in the 32-bit offsets
+    const rsrc_t rO = make_rsrc_rows(p.out, p.obytes, rb ? m0 : 0, p.ldo, rb);
+    const rsrc_t rX = make_rsrc_rows(EPM ? p.aux : p.out, EPM ? p.auxbytes : p.obytes, rb ? m0 : 0, EPM ? p.ldaux : p.ldo, rb);
     float* T = smem + wmn * (32 * TLD);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -107,7 +110,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16 (&
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lh) * TLD + li] = acc[i][j][r];
-        const unsigned row0 = (unsigned)((wm * TM + i) * 32 + erow);           // relative to m0
+        const unsigned row0 = (unsigned)(mrel + (wm * TM + i) * 32 + erow);    // relative to the descriptors' first row
         const unsigned obase = colok ? (row0 * (unsigned)p.ldo + (unsigned)col) * 4u : OOB;
         const unsigned xbase = colok ? (row0 * (unsigned)p.ldaux + (unsigned)col) * 4u : OOB;
         f32x4 axv[4], oldv[4], v[4];

@@ -52,7 +52,7 @@ namespace {
 // BN/ReLU prologue, and consumed by v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).  Both LDS
 // images are then K-contiguous bf16 rows of 2*BKT + 16 bytes (conflict-free ds_read_b128); k-major
 // weights are transposed while being staged, so the MFMA loop is the same for every kind.
-template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF, int KIND, bool BF>
+template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF, int KIND, bool BF, bool RB>
 __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const ConvGemmParams p) {
   constexpr bool TWO = KIND >= 2, KMAJOR = KIND >= 1;
   constexpr int LDH = 32 * KS + 8;       // bf16 image row stride (elements)
@@ -111,9 +111,10 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
 
   // source descriptors start at the first row this tile can touch (its rows, minus the 3x3 halo)
   const int halo_rows = p.taps > 1 ? p.W + 1 : 0;
-  const int mbase = m0 > halo_rows ? m0 - halo_rows : 0;
-  const rsrc_t rA0 = make_rsrc_rows(p.a.X0, p.a.bytes0, mbase, p.a.ld0);
-  const rsrc_t rA1 = make_rsrc_rows(TWO ? p.a.X1 : p.a.X0, TWO ? p.a.bytes1 : p.a.bytes0, mbase, TWO ? p.a.ld1 : p.a.ld0);
+  constexpr bool rb = RB;      // operand views beyond 2 GiB (host decision, device_utils.h)
+  const int mbase = (rb && m0 > halo_rows) ? m0 - halo_rows : 0;
+  const rsrc_t rA0 = make_rsrc_rows(p.a.X0, p.a.bytes0, mbase, p.a.ld0, rb);
+  const rsrc_t rA1 = make_rsrc_rows(TWO ? p.a.X1 : p.a.X0, TWO ? p.a.bytes1 : p.a.bytes0, mbase, TWO ? p.a.ld1 : p.a.ld0, rb);
   const rsrc_t rW = make_rsrc(p.Wt, p.wbytes);
 
   // ---- per-thread bookkeeping -----------------------------------------------------------------
@@ -396,12 +397,12 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
   }
 
   DDL_PROBE(p, 4);
-  conv_epilogue<BM, BN, WM, WN, NT, KIND>(p, acc, smem, m0, n0, tile_x, tid, ks, wmn);
+  conv_epilogue<BM, BN, WM, WN, NT, KIND, RB>(p, acc, smem, m0, n0, tile_x, tid, ks, wmn);
   DDL_PROBE(p, 8);
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF, int KIND, bool BF>
-void launch_inst(const ConvGemmParams& p, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF, int KIND, bool BF, bool RB>
+void launch_inst_rb(const ConvGemmParams& p, hipStream_t s) {
   constexpr bool KMAJOR = KIND >= 1;
   constexpr int BKT = 32 * KS;
   constexpr size_t b_elems = KMAJOR ? (size_t)BKT * (BN + 4) : (size_t)BN * (BKT + 4);
@@ -420,12 +421,19 @@ void launch_inst(const ConvGemmParams& p, hipStream_t s) {
   const size_t lds = m1t > m2 ? m1t : m2;
   static bool attr_set = false;
   if (!attr_set) {
-    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, KS, NBUF, PF, KIND, BF>),
+    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, KS, NBUF, PF, KIND, BF, RB>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     attr_set = true;
   }
   dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.N + BN - 1) / BN));
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, KS, NBUF, PF, KIND, BF>), grid, dim3(64 * WM * WN * KS), lds, s, p);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, KS, NBUF, PF, KIND, BF, RB>), grid, dim3(64 * WM * WN * KS), lds, s, p);
+}
+
+template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF, int KIND, bool BF>
+void launch_inst(const ConvGemmParams& p, hipStream_t s) {
+  // bf16 forms are instantiated rebasing only (not the headline path; halves the kernel count of this file)
+  if (BF || needs_rebase(p.a.bytes0, p.a.bytes1, p.obytes, p.auxbytes)) launch_inst_rb<BM, BN, WM, WN, KS, NBUF, PF, KIND, BF, true>(p, s);
+  else launch_inst_rb<BM, BN, WM, WN, KS, NBUF, PF, KIND, BF, BF>(p, s);       // (BF, RB) = (false, false)
 }
 
 template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF = 1>

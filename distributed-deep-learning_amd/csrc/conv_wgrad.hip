@@ -60,6 +60,7 @@ struct SrcDesc {
 __device__ __forceinline__ SrcDesc src_desc(const RowSrc& a, int row0) {
   SrcDesc d;
   d.two = a.X1 != nullptr;
+  // always rebased (a few dozen launches per step: the scalar arithmetic does not show), unlike the conv kernels
   d.row0 = row0 > 0 ? row0 : 0;
   d.r0 = make_rsrc_rows(a.X0, a.bytes0, d.row0, a.ld0);
   d.r1 = make_rsrc_rows(d.two ? a.X1 : a.X0, d.two ? a.bytes1 : a.bytes0, d.row0, d.two ? a.ld1 : a.ld0);

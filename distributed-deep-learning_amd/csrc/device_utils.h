@@ -32,7 +32,15 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
 // workgroup: row0 comes from blockIdx (scalar arithmetic, the descriptor stays in SGPRs), offsets are relative to
 // it, and the window one workgroup touches (its row tile plus a 3x3 halo) is a few megabytes.  The extent is
 // clamped below the OOB sentinel, so "offset = OOB" still selects nothing.
-__device__ __forceinline__ rsrc_t make_rsrc_rows(const float* p, long bytes, long row0, int ld) {
+// The 238 forward / data-gradient launches of a step sit on one dependent chain, and ~60 extra scalar instructions
+// at the top of each of them cost 0.06 ms per step (same-box A/B) - a run-time flag did not remove that - so the
+// conv kernels are instantiated twice (template bool RB) and the host picks: `needs_rebase` on the views' extents.
+// The weight-gradient and stem kernels (a few dozen launches beside the chain) always rebase.
+__host__ __device__ __forceinline__ bool needs_rebase(long a, long b = 0, long c = 0, long d = 0) {
+  return (a | b | c | d) > 0x7fffffffL;          // extents are non-negative
+}
+__device__ __forceinline__ rsrc_t make_rsrc_rows(const float* p, long bytes, long row0, int ld, bool rebase = true) {
+  if (!rebase) return make_rsrc(p, (unsigned)bytes);      // uniform branch; row0 is 0 by the caller's contract
   const long off = row0 * (long)ld * 4;
   long rem = bytes - off;
   rem = rem < 0 ? 0 : (rem > 0x7fffffffL ? 0x7fffffffL : rem);

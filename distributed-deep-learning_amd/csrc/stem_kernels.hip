@@ -81,8 +81,9 @@ __global__ void __launch_bounds__(256) stem_conv_fwd_kernel(const float* __restr
   const int aq = tid & 7, a_row0 = tid >> 3;
   // buffer addressing (device_utils.h): invalid rows / padding pixels select the OOB offset
   const int HW0 = H0 * W0;
-  const int bfirst = (int)(m0 / HW0);     // descriptor rebased at the first image of this tile (make_rsrc_rows)
-  const rsrc_t rX = make_rsrc_rows(xp, xp_bytes, (long)bfirst * H * W, 4);
+  const bool rb = needs_rebase(xp_bytes);
+  const int bfirst = rb ? (int)(m0 / HW0) : 0;     // descriptor rebased at the first image of this tile (make_rsrc_rows)
+  const rsrc_t rX = make_rsrc_rows(xp, xp_bytes, (long)bfirst * H * W, 4, rb);
   unsigned a_base[4];
   int a_iy0[4];
   bool a_ok[4];
@@ -319,11 +320,12 @@ __global__ void __launch_bounds__(256) stem_wgrad_kernel(const float* __restrict
   const int segs_per_img = H0 * XS;
 
   // descriptors rebased at the first image of this workgroup's chunk (conv0's output passes 2 GiB at ~650 images)
-  const int b0 = seg_b / segs_per_img;
   const long nimg = nseg / segs_per_img;
   const long y_bytes = nimg * H0 * W0 * NC0 * 4L;                                  // B*H0*W0*64 floats
-  const rsrc_t rG = make_rsrc_rows(g0, y_bytes, (long)b0 * H0 * W0, NC0), rY = make_rsrc_rows(y0, y_bytes, (long)b0 * H0 * W0, NC0);
-  const rsrc_t rX = make_rsrc_rows(xp, nimg * H * W * 16L, (long)b0 * H * W, 4);
+  const bool rb = needs_rebase(y_bytes);
+  const int b0 = rb ? seg_b / segs_per_img : 0;
+  const rsrc_t rG = make_rsrc_rows(g0, y_bytes, (long)b0 * H0 * W0, NC0, rb), rY = make_rsrc_rows(y0, y_bytes, (long)b0 * H0 * W0, NC0, rb);
+  const rsrc_t rX = make_rsrc_rows(xp, nimg * H * W * 16L, (long)b0 * H * W, 4, rb);
   const int dq = 4 * (tid & 15);
   const f32x4 c0 = ld4(k0 + dq), c1 = ld4(k1 + dq), c2 = ld4(k2 + dq);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
