@@ -30,7 +30,10 @@
 // writes) and are read with four conflict-free ds_read_b32 instead of being transposed.
 // fp32 MFMA issues once per 64 cycles, so LDS and VALU (the fused prologue) are far from
 // limiting; what matters is keeping every SIMD's MFMA queue fed.
+#include <cstdio>
 #include <cstdlib>
+#include <string>
+#include <vector>
 
 #include "conv_params.h"
 #include "ddl_kernels.h"
@@ -499,9 +502,38 @@ void launch_by_id(int id, const ConvGemmParams& p, hipStream_t s) {
 //  * 128-column family: 64-row tiles beat 128-row tiles up to ~1500 row tiles (smaller tail when
 //    tiles are dealt over the resident slots), single LDS buffer (4 workgroups / CU) >= double;
 //  * 32-column family (3x3 forward): 128 rows for the big maps, 32 rows x 4-way K split below.
+// DDL_CFG_RULES="kind:taps:minM:maxM:cfg,..." overrides the heuristic for matching problems (first match wins).
+// Tile choices have to be judged INSIDE the step (next to the weight-gradient chain a configuration that wins the
+// microbenchmark can lose - README "dead ends"); this is the hook bench/r2/cfg_rules_ab.sh drives.
+struct CfgRule { int kind, taps; long lo, hi; int cfg; };
+static const std::vector<CfgRule>& cfg_rules() {
+  static const std::vector<CfgRule> rules = [] {
+    std::vector<CfgRule> r;
+    const char* e = getenv("DDL_CFG_RULES");
+    if (e == nullptr) return r;
+    std::string s(e);
+    size_t pos = 0;
+    while (pos < s.size()) {
+      size_t end = s.find(',', pos);
+      if (end == std::string::npos) end = s.size();
+      CfgRule c{};
+      if (sscanf(s.substr(pos, end - pos).c_str(), "%d:%d:%ld:%ld:%d", &c.kind, &c.taps, &c.lo, &c.hi, &c.cfg) == 5 &&
+          c.cfg >= 0 && c.cfg < NUM_CFG)
+        r.push_back(c);
+      pos = end + 1;
+    }
+    return r;
+  }();
+  return rules;
+}
+
 int pick_cfg(const ConvGemmParams& p, int force) {
   const int M = p.M, N = p.N;
   if (force >= 1000 && force < 1000 + NUM_CFG) return force - 1000;
+  if (!force) {
+    for (const CfgRule& c : cfg_rules())
+      if (c.kind == p.kind && c.taps == p.taps && M >= c.lo && M <= c.hi) return c.cfg;
+  }
   int bm = (force == 32 || force == 64 || force == 128) ? force : 0;
   if (N > 32) {
     if (!bm && M <= 2048) {
