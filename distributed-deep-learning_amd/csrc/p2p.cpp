@@ -20,6 +20,7 @@
 // one GPU), where transfers are host-staged and synchronous.
 #include "torch_hip.h"
 
+#include <cstdlib>
 #include <ATen/hip/HIPEvent.h>
 #include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 #include <torch/csrc/distributed/c10d/Types.hpp>
@@ -54,8 +55,12 @@ class P2PEngine {
     const int world = pg_->getSize();
     for (auto& t : sends) TORCH_CHECK(t.is_cuda() && t.is_contiguous(), "p2p: contiguous GPU tensors only");
     for (auto& t : recvs) TORCH_CHECK(t.is_cuda() && t.is_contiguous(), "p2p: contiguous GPU tensors only");
-    for (int64_t r : send_peers) TORCH_CHECK(r >= 0 && r < world && r != pg_->getRank(), "p2p: bad send peer ", r);
-    for (int64_t r : recv_peers) TORCH_CHECK(r >= 0 && r < world && r != pg_->getRank(), "p2p: bad recv peer ", r);
+    // DDL_P2P_ALLOW_SELF=1: a rank may address itself (RCCL runs a coalesced self send + receive as a local copy) -
+    // the one-GPU rehearsal of this engine on the real RCCL (bench/p2p_self_probe.py, tests/test_gpu_dist.py)
+    static const bool allow_self = [] { const char* e = getenv("DDL_P2P_ALLOW_SELF"); return e && e[0] == '1'; }();
+    const int me = pg_->getRank();
+    for (int64_t r : send_peers) TORCH_CHECK(r >= 0 && r < world && (r != me || allow_self), "p2p: bad send peer ", r);
+    for (int64_t r : recv_peers) TORCH_CHECK(r >= 0 && r < world && (r != me || allow_self), "p2p: bad recv peer ", r);
     const at::Tensor& any = sends.empty() ? recvs[0] : sends[0];
     const Stream main = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(any.device().index());
     const Stream where = serialize_ ? main : p2p_;          // --debug-sync: everything on the compute stream

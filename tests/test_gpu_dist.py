@@ -340,6 +340,20 @@ def test_bench_rccl_world_of_one_forced_collectives(tmp_path, extra):
 
 
 @pytest.mark.gpu
+def test_native_p2p_engine_on_rccl_with_self_transfers(tmp_path):
+    """csrc/p2p.cpp on the real RCCL: a world of one whose every group is a coalesced send + receive to the rank itself
+    (DDL_P2P_ALLOW_SELF=1; RCCL runs it as a local copy) - tickets in order, payload fenced behind the compute stream,
+    compute-stream waits, drain, the timing source and the --debug-sync form.  The pipeline schedules themselves run on
+    the gloo twin of this channel (two GPUs are needed for a real peer)."""
+    os.environ["DDL_P2P_ALLOW_SELF"] = "1"
+    try:
+        out = _torchrun(1, "bench/p2p_self_probe.py", [], tmp_path)
+    finally:
+        os.environ.pop("DDL_P2P_ALLOW_SELF", None)
+    assert "P2P SELF OK" in out and "timed group" in out, out[-2000:]
+
+
+@pytest.mark.gpu
 def test_native_reducer_matches_python_reducer(tmp_path):
     """csrc/reducer.cpp vs the Python bucket path of parallel/dp.py: same seed, same batches, RCCL world of one
     with forced collectives, eager launches so the engine's per-unit callbacks drive param_ready; the native
