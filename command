@@ -31,3 +31,11 @@ python debug.py
 ### headline benchmark
 python bench.py --gpus 1
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 bench.py --gpus 8
+
+### round 2: balanced pipelines and throughput-sized shapes
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 pp.py --split-points auto --schedule 1f1b
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 ddp_n_pp.py --pp-size 2 --split-points auto --batch-size 240 --num-microbatches 8
+python debug.py --auto-stages 2 4 --micro-batch 30
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 bench.py --gpus 2 --mode pp --preset mi355x
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 bench.py --gpus 8 --mode ddpnpp --pp-size 2 --preset mi355x-large
+python bench.py --batch-per-gpu 1024        # tensors beyond 2 GiB
