@@ -65,7 +65,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
                  "-Wno-unused-result", "-Wno-deprecated-declarations",
                  f"-I{CSRC}", f"-I{sysconfig.get_paths()['include']}"] + [f"-I{i}" for i in incs]
     extra = os.environ.get("DDL_BUILD_DEFINES", "").split()      # e.g. -DDDL_PHASE_PROBE (bench/phase_probe.py)
-    hip_flags += extra
+    hip_flags += extra + os.environ.get("DDL_HIP_FLAGS", "").split()   # extra device-compiler flags (experiments)
     cpp_flags += extra
     jobs = []
     for src in sorted(CSRC.glob("*.hip")):
