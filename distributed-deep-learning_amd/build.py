@@ -96,7 +96,8 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     if todo or not OUT.exists() or force:
         _run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-o", str(OUT),
               *[str(o) for o in objs], f"-L{tlib}", f"-Wl,-rpath,{tlib}",
-              "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python"])
+              "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python",
+              "-lz"])          # zlib: csrc/png_loader.cpp
         if verbose:
             print(f"[ddl.build] linked {OUT}", flush=True)
     return OUT

@@ -36,7 +36,8 @@ class TrainConfig:
     image_size: int = 224
     num_classes: int = 5
     batch_size: int = 30                # per-process batch (single 30, ddp 15, pp 30, ddpnpp 10)
-    num_workers: int = 2
+    num_workers: int = 2                # decode threads of the native PNG loader / DataLoader worker processes
+    native_loader: str = "auto"         # auto | off: C++ threaded PNG decode into pinned batches (csrc/png_loader.cpp)
     device_data: bool = False           # generate synthetic batches directly on the GPU (benchmarks)
     cache_dataset: str = "auto"         # auto | device | off: decode once, keep the uint8 dataset in HBM (data.ResidentLoader)
     cache_budget_gb: float = 16.0       # auto: largest dataset (GB of uint8) kept resident

@@ -67,6 +67,7 @@ void register_conv_ops(pybind11::module_& m);   // conv_bindings.cpp
 void register_stem_ops(pybind11::module_& m);   // stem_bindings.cpp
 void register_reducer(pybind11::module_& m);    // reducer.cpp
 void register_p2p(pybind11::module_& m);        // p2p.cpp
+void register_io(pybind11::module_& m);         // png_loader.cpp
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "hand-written gfx950 (MI355X) kernels of the ddl framework";
@@ -77,4 +78,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   register_stem_ops(m);
   register_reducer(m);
   register_p2p(m);
+  register_io(m);
 }

@@ -189,6 +189,54 @@ class HostLoader:
         return sizes
 
 
+def native_png_ok(dataset, mode: str = "auto") -> bool:
+    """True when ``dataset`` can be read by the C++ loader: an ``AptosDataset`` handing out raw uint8 images
+    (no transform) and the extension built.  ``mode == 'off'`` keeps the torch DataLoader."""
+    if mode == "off" or not isinstance(dataset, AptosDataset) or dataset.transform is not None or len(dataset) == 0:
+        return False
+    from .ops import have_ext
+    return have_ext()
+
+
+class NativePngLoader:
+    """``HostLoader`` contract on the C++ thread pool (csrc/png_loader.cpp) instead of DataLoader worker processes.
+
+    Every batch is decoded by all threads at once straight into its final (pinned) uint8 ``[m,3,H,W]`` buffer, two
+    batches ahead of the consumer; the consumer blocks with the GIL released.  Files the native decoder does not
+    cover (16-bit, interlaced) come back as slot numbers and are decoded here with PIL, so any PNG the reference's
+    ``read_image`` accepts still loads."""
+
+    def __init__(self, dataset: AptosDataset, batch_size: int, sampler, num_workers: int = 2,
+                 drop_last: bool = True, pin_memory: bool = False, depth: int = 2) -> None:
+        from .ops import load_ext
+        self.dataset, self.batch_size, self.sampler, self.drop_last = dataset, batch_size, sampler, drop_last
+        self.paths = [str(dataset.root_dir / f"{n}.png") for n in dataset.names]
+        self.labels = torch.tensor(dataset.labels, dtype=torch.int64)
+        ext = load_ext()
+        w, h = ext.png_info(self.paths[0])[:2]
+        self.threads = max(int(num_workers), 1)
+        self._loader = ext.PngLoader(self.paths, h, w, self.threads, depth, bool(pin_memory))
+
+    def set_epoch(self, epoch: int) -> None:
+        if hasattr(self.sampler, "set_epoch"):
+            self.sampler.set_epoch(epoch)
+
+    def batch_sizes(self) -> List[int]:
+        full, rem = divmod(len(self.sampler), self.batch_size)
+        return [self.batch_size] * full + ([rem] if rem and not self.drop_last else [])
+
+    def __len__(self) -> int:
+        return len(self.batch_sizes())
+
+    def __iter__(self):
+        self._loader.start_epoch([int(i) for i in self.sampler], self.batch_size, self.drop_last)
+        while self._loader.batches_left():
+            x, idx, unsupported = self._loader.next()
+            for slot in unsupported:
+                x[slot].copy_(read_png(self.paths[int(idx[slot])]))
+            yield x, self.labels[idx]
+
+
 class DevicePrefetcher:
     """Host -> device staging one batch ahead on a dedicated copy stream.
 
@@ -285,7 +333,7 @@ class ResidentLoader:
 
     def __init__(self, dataset: Dataset, batch_size: int, sampler: ShardedSampler, device,
                  num_workers: int = 2, drop_last: bool = True, needs_input: bool = True,
-                 shard_fill: bool = True, chunk: int = 256) -> None:
+                 shard_fill: bool = True, chunk: int = 256, native: str = "auto") -> None:
         from . import comm
         self.batch_size, self.sampler, self.drop_last = batch_size, sampler, drop_last
         self.device = torch.device(device)
@@ -299,9 +347,15 @@ class ResidentLoader:
         self.labels = torch.empty(n, dtype=torch.int64, device=self.device)
         chunk = min(chunk, per)
         pin = self.device.type == "cuda"
-        it = iter(DataLoader(torch.utils.data.Subset(dataset, range(lo, hi)), batch_size=chunk, shuffle=False,
-                             num_workers=num_workers if hi - lo > chunk else 0, collate_fn=_collate_uint8,
-                             pin_memory=pin)) if hi > lo else iter(())
+        if hi <= lo:
+            it = iter(())
+        elif native_png_ok(dataset, native):           # C++ thread pool, decoded straight into pinned chunks
+            it = iter(NativePngLoader(dataset, chunk, range(lo, hi), max(num_workers, 1), drop_last=False,
+                                      pin_memory=pin))
+        else:
+            it = iter(DataLoader(torch.utils.data.Subset(dataset, range(lo, hi)), batch_size=chunk, shuffle=False,
+                                 num_workers=num_workers if hi - lo > chunk else 0, collate_fn=_collate_uint8,
+                                 pin_memory=pin))
         self.fill_decoded = hi - lo
         for k in range(-(-per // chunk)):              # same number of rounds on every rank
             xb, yb = next(it, (None, None))
@@ -417,11 +471,14 @@ def build_loaders(cfg, dp_rank: int = 0, dp_size: int = 1, device=None, shared_o
     drop_train = cfg.strategy in ("pp", "ddpnpp")
     drop_test = (cfg.strategy in ("pp", "ddpnpp")) and not cfg.eval_all
     if resident_fits(cfg, len(train_ds) + len(test_ds), device):
-        return (ResidentLoader(train_ds, cfg.batch_size, tr_s, device, cfg.num_workers, drop_train, needs_input),
-                ResidentLoader(test_ds, cfg.batch_size, te_s, device, cfg.num_workers, drop_test, needs_input))
-    train = HostLoader(train_ds, cfg.batch_size, tr_s, cfg.num_workers, drop_last=drop_train, pin_memory=pin)
-    test = HostLoader(test_ds, cfg.batch_size, te_s, cfg.num_workers,
-                      drop_last=(cfg.strategy in ("pp", "ddpnpp")) and not cfg.eval_all, pin_memory=pin)
+        return (ResidentLoader(train_ds, cfg.batch_size, tr_s, device, cfg.num_workers, drop_train, needs_input,
+                               native=cfg.native_loader),
+                ResidentLoader(test_ds, cfg.batch_size, te_s, device, cfg.num_workers, drop_test, needs_input,
+                               native=cfg.native_loader))
+    # host path: the C++ PNG thread pool for the real dataset, torch DataLoader workers for anything else
+    Loader = NativePngLoader if native_png_ok(train_ds, cfg.native_loader) else HostLoader
+    train = Loader(train_ds, cfg.batch_size, tr_s, cfg.num_workers, drop_last=drop_train, pin_memory=pin)
+    test = Loader(test_ds, cfg.batch_size, te_s, cfg.num_workers, drop_last=drop_test, pin_memory=pin)
     return train, test
 
 

@@ -79,3 +79,29 @@ def test_fused_adam_flat_kernel(dev, wd):
         torch.testing.assert_close(arena.flat_param.cpu(), p_ref, rtol=2e-5, atol=1e-6)
         torch.testing.assert_close(opt.exp_avg_sq.cpu(), v_ref, rtol=1e-5, atol=1e-9)
     assert float(opt.step_t) == 3.0 and arena.flat_grad.abs().sum() == 0      # zero_grad fused in
+
+
+def test_native_png_loader_feeds_the_gpu(dev, tmp_path):
+    """csrc/png_loader.cpp on the GPU box: pinned batches through the copy-stream prefetcher, and the HBM-resident
+    dataset filled by the same thread pool, both equal to the PIL-decoded dataset."""
+    from ddl import data
+    from ddl.config import TrainConfig
+    root = data.make_png_dataset(tmp_path, 26, 10, image_size=32)
+    cfg = TrainConfig(strategy="single", batch_size=8, synthetic="off", data_dir=str(root), num_workers=4, image_size=32)
+    ds, _ = data.build_datasets(cfg)
+    host, _ = data.build_loaders(cfg.replace(cache_dataset="off"), device=dev)
+    assert isinstance(host, data.NativePngLoader)
+    for epoch in (0, 1):
+        host.set_epoch(epoch)
+        order = list(host.sampler)
+        seen = 0
+        for x, y, n in data.DevicePrefetcher(host, dev):
+            assert x.is_cuda and x.dtype == torch.uint8 and n == x.shape[0]
+            for k in range(n):
+                img, label = ds[order[seen + k]]
+                assert torch.equal(x[k].cpu(), img) and int(y[k]) == label
+            seen += n
+        assert seen == 26                      # single keeps the ragged tail (single.py DataLoader default)
+    res, _ = data.build_loaders(cfg, device=dev)
+    assert isinstance(res, data.ResidentLoader) and res.images.is_cuda
+    assert all(torch.equal(res.images[i].cpu(), ds[i][0]) for i in range(len(ds)))
