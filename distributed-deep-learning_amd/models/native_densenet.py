@@ -723,6 +723,11 @@ class NativeDenseNetStage(nn.Module):
         latency-bound 10-25 us kernel; keep the per-layer kernels where one layer already fills the chip."""
         g = self._wgrad_group
         if g == "auto":
+            for rule in os.environ.get("DDL_WGRAD_GROUPS", "").split(","):     # "minM:G,..." first match wins (experiments)
+                if rule:
+                    m, gg = rule.split(":")
+                    if M >= int(m):
+                        return max(1, min(int(gg), 24))
             return 4
         return max(1, min(int(g), 24))
 
