@@ -341,22 +341,32 @@ int launch_rows_op(int mode, long M, int C, const float* in, int ldi, const floa
 // ---------------------------------------------------------------------------------------------
 // head forward: pooled[b][c] = mean_{hw} relu(sc*x+sh).  grid = (B, C/256), thread = channel.
 // ---------------------------------------------------------------------------------------------
+// 64 channels x 4 pixel groups per workgroup: the 49 (or H*W) dependent loads of one channel are split over four
+// threads and reduced through LDS in a fixed order (12.9 -> ~5 us on the 7x7 maps at batch 30: the old form ran
+// 30 x 4 workgroups with one serial chain of H*W loads per thread).
 __global__ void __launch_bounds__(256) bnrelu_gap_fwd_kernel(const float* __restrict__ x, int ldx, int HW,
                                                              const float* __restrict__ sc,
                                                              const float* __restrict__ sh,
                                                              float* __restrict__ pooled, int C) {
-  const int c = blockIdx.y * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
   const long b = blockIdx.x;
-  const float s = sc[c], t = sh[c];
   float acc = 0.f;
-  for (int i = 0; i < HW; ++i) acc += fmaxf(fmaf(s, x[(b * HW + i) * ldx + c], t), 0.f);
-  pooled[b * C + c] = acc / (float)HW;
+  if (c < C) {
+    const float s = sc[c], t = sh[c];
+    const float* xb = x + b * HW * (long)ldx + c;
+#pragma unroll 4
+    for (int i = g; i < HW; i += 4) acc += fmaxf(fmaf(s, xb[(long)i * ldx], t), 0.f);
+  }
+  part[g][cl] = acc;
+  __syncthreads();
+  if (g == 0 && c < C) pooled[b * C + c] = (((part[0][cl] + part[1][cl]) + part[2][cl]) + part[3][cl]) / (float)HW;
 }
 
 void launch_bnrelu_gap_fwd(const float* x, int ldx, int B, int HW, const float* sc, const float* sh,
                            float* pooled, int C, hipStream_t s) {
-  hipLaunchKernelGGL(bnrelu_gap_fwd_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, s, x, ldx, HW, sc, sh,
+  hipLaunchKernelGGL(bnrelu_gap_fwd_kernel, dim3(B, (C + 63) / 64), dim3(256), 0, s, x, ldx, HW, sc, sh,
                      pooled, C);
 }
 

@@ -461,15 +461,25 @@ __global__ void __launch_bounds__(256) stem_wgrad_reduce_kernel(const float* __r
 // classifier: logits[b][n] = pooled[b][:] . W[n][:] + bias[n]   (K = 1024, N = num_classes, tiny)
 // one workgroup per batch row, one wave per output (strided), wave-shuffle reduction.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ void __launch_bounds__(512) linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ out,
                                                          int K, int N) {
+  // eight waves, one output each per pass; every lane keeps four independent partial sums so that its loads are
+  // in flight together (the old form: 16 dependent load+fma rounds per output, two outputs on wave 0 at N = 5)
   const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const float* xr = x + (long)b * K;
-  for (int n = wid; n < N; n += 4) {
+  for (int n = wid; n < N; n += 8) {
     const float* wr = w + (long)n * K;
-    float acc = 0.f;
-    for (int k = lane; k < K; k += 64) acc = fmaf(xr[k], wr[k], acc);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int k = lane;
+    for (; k + 192 < K; k += 256) {
+      a0 = fmaf(xr[k], wr[k], a0);
+      a1 = fmaf(xr[k + 64], wr[k + 64], a1);
+      a2 = fmaf(xr[k + 128], wr[k + 128], a2);
+      a3 = fmaf(xr[k + 192], wr[k + 192], a3);
+    }
+    for (; k < K; k += 64) a0 = fmaf(xr[k], wr[k], a0);
+    float acc = (a0 + a1) + (a2 + a3);
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if (lane == 0) out[(long)b * N + n] = acc + (bias != nullptr ? bias[n] : 0.f);
   }
@@ -490,6 +500,7 @@ __global__ void __launch_bounds__(256) linear_bwd_kernel(const float* __restrict
   if (t < (long)N * K) {
     const int n = (int)(t / K), k = (int)(t - (long)n * K);
     float acc = 0.f;
+#pragma unroll 8
     for (int b = 0; b < B; ++b) acc = fmaf(dy[b * N + n], x[(long)b * K + k], acc);
     dW[t] += acc;
   }
@@ -588,7 +599,7 @@ void launch_stem_wgrad(const float* g0, const float* y0, const float* k0, const 
 
 void launch_linear_fwd(const float* x, const float* w, const float* bias, float* out, int B, int K, int N,
                        hipStream_t s) {
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3(B), dim3(256), 0, s, x, w, bias, out, K, N);
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(B), dim3(512), 0, s, x, w, bias, out, K, N);
 }
 
 void launch_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* dW, float* db, int B,

@@ -92,6 +92,19 @@ def cross_entropy_with_preds(logits: torch.Tensor, targets: torch.Tensor) -> Tup
     return F.cross_entropy(logits, targets), logits.detach().argmax(dim=1)
 
 
+def cross_entropy_backward(logits: torch.Tensor, targets: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``loss = cross_entropy(logits, targets); loss.backward()`` in one go, returning ``(loss.detach(), preds)``.
+    On the GPU the fused kernel's d(loss)/d(logits) is handed straight to ``logits.backward`` - no autograd node for
+    the loss, so no ones_like fill and no ``dlogits * 1`` launch in the captured step (bit-identical gradients)."""
+    if logits.is_cuda:
+        loss, dlogits, preds = require_ext().ce_fwd_bwd(logits.detach().contiguous(), targets.contiguous())
+        logits.backward(dlogits)
+        return loss, preds
+    loss, preds = cross_entropy_with_preds(logits, targets)
+    loss.backward()
+    return loss.detach(), preds
+
+
 def cross_entropy(logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
     return cross_entropy_with_preds(logits, targets)[0]
 

@@ -54,9 +54,8 @@ class GraphedTrainStep:
         out = self.model(x)
         if after_forward is not None:
             after_forward()
-        loss, preds = ops.cross_entropy_with_preds(out, y)
-        loss.backward()
-        return loss.detach(), out.detach(), preds
+        loss, preds = ops.cross_entropy_backward(out, y)
+        return loss, out.detach(), preds
 
     def _eager(self, x, y):
         dp, prof = self.dp, self.profiler
@@ -109,9 +108,8 @@ class GraphedTrainStep:
             with torch.cuda.graph(c.graph, **mode):
                 self.optimizer.zero_grad()
                 out, cuts = self.model.forward_phased(c.x)
-                loss, c.preds = ops.cross_entropy_with_preds(out, c.y)
-                loss.backward()
-                c.loss, c.out = loss.detach(), out.detach()
+                c.loss, c.preds = ops.cross_entropy_backward(out, c.y)
+                c.out = out.detach()
                 self._check_joined()
             for y_mid, leaf in reversed(cuts):          # one graph per earlier phase
                 g = torch.cuda.CUDAGraph()
