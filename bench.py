@@ -335,6 +335,7 @@ def main() -> None:
                     # (every bucket behind the whole backward), one cut, a cut at every dense block
                     phase_sweep = {"default": round(step_ms, 3)}
                     for name, gp in (("none", ""), ("denseblock3", "denseblock3"),
+                                     ("blocks 3,2,1", "denseblock3,denseblock2,denseblock1"),
                                      ("every block", "denseblock4,denseblock3,denseblock2,denseblock1")):
                         s2 = make_strategy(a.bucket_mb, gp)
                         s2.model.train()
