@@ -15,6 +15,7 @@
 //  * `rows_op` is the single skeleton for the pixel-touching glue ops: a workgroup owns a tile of
 //    rows, each thread a fixed float4 channel column, so per-channel sums stay in registers and
 //    one LDS pass combines the row lanes.
+#include "conv_params.h"
 #include "ddl_kernels.h"
 #include "device_utils.h"
 
@@ -230,6 +231,8 @@ struct RowsOpParams {
   int ldo;
   int H, W;          // spatial size of the un-pooled tensor (pool / gap modes)
   float* stats;      // [gridDim.x][2][C] or nullptr
+  long long* acc;    // COPY_STATS alternative: fixed-point accumulators [R][2][acc_ld] (conv_params.h FusedBn) or nullptr
+  int acc_ld;
   int rows_per_wg;
 };
 
@@ -292,7 +295,7 @@ __global__ void __launch_bounds__(256) rows_op_kernel(const RowsOpParams p) {
       }
     }
   }
-  if (p.stats != nullptr) {
+  if (p.stats != nullptr || p.acc != nullptr) {
     if (rl < lanes) {
       st4(smem + (rl * 2 + 0) * p.C + c, s1);
       st4(smem + (rl * 2 + 1) * p.C + c, s2);
@@ -301,7 +304,13 @@ __global__ void __launch_bounds__(256) rows_op_kernel(const RowsOpParams p) {
     for (int i = threadIdx.x; i < 2 * p.C; i += 256) {
       float s = 0.f;
       for (int l = 0; l < lanes; ++l) s += smem[l * 2 * p.C + i];
-      p.stats[(long)blockIdx.x * 2 * p.C + i] = s;
+      if (p.acc != nullptr) {       // the consumer derives the BN statistics itself: no table, no bn_prep launch
+        const int which = i >= p.C, cc = i - which * p.C;
+        __hip_atomic_fetch_add(p.acc + (long)(2 * (blockIdx.x & (kStatReplicas - 1)) + which) * p.acc_ld + cc,
+                               __double2ll_rn((double)s * kStatScale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        p.stats[(long)blockIdx.x * 2 * p.C + i] = s;
+      }
     }
   }
 }
@@ -316,7 +325,7 @@ static int rows_op_launch(const RowsOpParams& p0, hipStream_t s) {
   rows = (rows + lanes - 1) / lanes * lanes;
   p.rows_per_wg = (int)rows;
   const int grid = (int)((p.M + rows - 1) / rows);
-  const size_t lds = p.stats ? (size_t)lanes * 2 * p.C * sizeof(float) : 0;
+  const size_t lds = (p.stats || p.acc) ? (size_t)lanes * 2 * p.C * sizeof(float) : 0;
   hipLaunchKernelGGL(rows_op_kernel, dim3(grid), dim3(256), lds, s, p);
   return grid;
 }
@@ -331,10 +340,10 @@ int rows_op_grid(long M, int C) {
 
 int launch_rows_op(int mode, long M, int C, const float* in, int ldi, const float* x, int ldx,
                    const float* sc, const float* sh, float* out, int ldo, int H, int W, float* stats,
-                   hipStream_t s) {
+                   long long* acc, int acc_ld, hipStream_t s) {
   RowsOpParams p;
   p.mode = mode; p.M = M; p.C = C; p.in = in; p.ldi = ldi; p.x = x; p.ldx = ldx; p.sc = sc; p.sh = sh;
-  p.out = out; p.ldo = ldo; p.H = H; p.W = W; p.stats = stats; p.rows_per_wg = 0;
+  p.out = out; p.ldo = ldo; p.H = H; p.W = W; p.stats = stats; p.acc = acc; p.acc_ld = acc_ld; p.rows_per_wg = 0;
   return rows_op_launch(p, s);
 }
 

@@ -467,7 +467,7 @@ void bn_bwd_prep(const at::Tensor& partials, double count, const at::Tensor& cha
 
 // pixel glue ops (see bn_kernels.hip rows_op); returns the statistics table or an empty tensor
 at::Tensor rows_op(int64_t mode, int64_t M, const at::Tensor& in, const OptT& x, const OptT& sc, const OptT& sh,
-                   at::Tensor out, int64_t H, int64_t W, bool want_stats) {
+                   at::Tensor out, int64_t H, int64_t W, bool want_stats, const OptT& acc_out) {
   ddl::DeviceGuard guard(in.device());
   const int64_t C = out.size(1);
   TORCH_CHECK(mode >= 0 && mode <= 4, "rows_op mode");
@@ -495,8 +495,15 @@ at::Tensor rows_op(int64_t mode, int64_t M, const at::Tensor& in, const OptT& x,
     stats = at::empty({ddl::rows_op_grid(M, (int)C), 2, C}, out.options());
     sp = stats.data_ptr<float>();
   }
+  long long* accp = nullptr; int acc_ld = 0;
+  if (acc_out.has_value()) {      // copy mode: channel sums into fixed-point accumulators instead of a table
+    TORCH_CHECK(mode == 0 && !want_stats, "rows_op: acc_out is the copy mode's alternative to the statistics table");
+    check_acc(*acc_out, C, "acc_out");
+    accp = reinterpret_cast<long long*>(acc_out->data_ptr<int64_t>());
+    acc_ld = (int)acc_out->stride(1);
+  }
   ddl::launch_rows_op((int)mode, M, (int)C, inp, ldi, xp, ldx, scp, shp, out.data_ptr<float>(), (int)out.stride(0),
-                      (int)H, (int)W, sp, cur_stream());
+                      (int)H, (int)W, sp, accp, acc_ld, cur_stream());
   return stats;
 }
 
@@ -553,6 +560,9 @@ void register_conv_ops(pybind11::module_& m) {
       .def("__len__", &SlabQueue::size);
   m.def("bn_prep", &bn_prep, "finalize channel statistics, derive BN scale/shift, update running stats");
   m.def("bn_bwd_prep", &bn_bwd_prep, "BN backward per-channel coefficients, dgamma/dbeta");
-  m.def("rows_op", &rows_op, "pixel glue ops (copy+stats, pool fwd/bwd, gap bwd, deferred-term apply)");
+  m.def("rows_op", &rows_op, "pixel glue ops (copy+stats, pool fwd/bwd, gap bwd, deferred-term apply)",
+        pybind11::arg("mode"), pybind11::arg("M"), pybind11::arg("in"), pybind11::arg("x"), pybind11::arg("sc"),
+        pybind11::arg("sh"), pybind11::arg("out"), pybind11::arg("H"), pybind11::arg("W"), pybind11::arg("want_stats"),
+        pybind11::arg("acc_out") = c10::nullopt);
   m.def("bnrelu_gap_fwd", &bnrelu_gap_fwd, "BN+ReLU+global average pool");
 }

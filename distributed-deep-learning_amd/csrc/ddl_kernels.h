@@ -59,7 +59,7 @@ void launch_bn_acc_finalize(const long long* acc, int acc_ld, int c0, int n, dou
                             float* chan_var, float* chan_rstd, hipStream_t s);
 int rows_op_grid(long M, int C);
 int launch_rows_op(int mode, long M, int C, const float* in, int ldi, const float* x, int ldx,
-                   const float* sc, const float* sh, float* out, int ldo, int H, int W, float* stats,
+                   const float* sc, const float* sh, float* out, int ldo, int H, int W, float* stats, long long* acc, int acc_ld,
                    hipStream_t s);
 void launch_bnrelu_gap_fwd(const float* x, int ldx, int B, int HW, const float* sc, const float* sh,
                            float* pooled, int C, hipStream_t s);

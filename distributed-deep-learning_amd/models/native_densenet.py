@@ -77,21 +77,19 @@ class _BlockFn(torch.autograd.Function):
         bn2 = torch.empty(L, 5, MID, **f32)                 # mean2, var2, rstd2, sc2, sh2
         h = torch.empty(L, M, MID, **f32)                   # bottleneck activations (pre-BN2)
         x2d = x_in.reshape(M, C0)
-        part = ext.rows_op(0, M, x2d, None, None, None, buf2d[:, :C0], H, W, train)
         if train and unit.stage.fused_stats:
             # Fused statistics: channel sums live in int64 fixed-point accumulators (integer atomics from the
-            # producing conv's epilogue); each conv derives its BN scale / shift from them in its prologue and
-            # its workgroup (0,0) writes the tables backward needs + the running statistics.  No bn_prep
-            # launches between the convolutions (2 per layer on the critical path otherwise).
+            # producing kernel's epilogue - the copy of the incoming channels included); each conv derives its BN
+            # scale / shift from them in its prologue and its workgroup (0,0) writes the tables backward needs +
+            # the running statistics.  No bn_prep launches between the kernels of the block.
             R = ext.STAT_REPLICAS
             acc = torch.zeros(R * 2 * (Cf + L * MID), dtype=torch.int64, device=dev)
             acc_b, acc_h = acc[:R * 2 * Cf].view(R, 2, Cf), acc[R * 2 * Cf:].view(R, 2, L * MID)
-            ext.bn_prep(part, 0, C0, float(M), stats[0], stats[1], stats[2], None, None, None, None, None, None,
-                        C0, BN_MOMENTUM, BN_EPS, True)            # the incoming channels: table statistics
+            ext.rows_op(0, M, x2d, None, None, None, buf2d[:, :C0], H, W, False, acc_out=acc_b)
             for l, lay in enumerate(unit.layers):
                 C = C0 + GROWTH * l
                 hs = slice(l * MID, (l + 1) * MID)
-                ext.conv_fwd_fused(buf2d[:, :C], acc_b, C if l == 0 else C - GROWTH, lay.g1, lay.b1, lay.rm1, lay.rv1,
+                ext.conv_fwd_fused(buf2d[:, :C], acc_b, 0 if l == 0 else C - GROWTH, lay.g1, lay.b1, lay.rm1, lay.rv1,
                                    sc1[l], sh1[l], stats[0], stats[1], stats[2], float(M), BN_MOMENTUM, BN_EPS,
                                    M, H, W, 1, lay.w1, h[l], acc_h[:, :, hs], 0, bf)
                 ext.conv_fwd_fused(h[l], acc_h[:, :, hs], 0, lay.g2, lay.b2, lay.rm2, lay.rv2, bn2[l, 3], bn2[l, 4],
@@ -103,6 +101,7 @@ class _BlockFn(torch.autograd.Function):
             ctx.geom = (B, H, W, C0)
             ctx.save_for_backward(buf, stats, sc1, sh1, bn2, h)
             return buf
+        part = ext.rows_op(0, M, x2d, None, None, None, buf2d[:, :C0], H, W, train)
         new0, n_new = 0, C0
         for l, lay in enumerate(unit.layers):
             C = C0 + GROWTH * l

@@ -150,6 +150,27 @@ def test_rows_op_copy_stats(dev, M, C, Cf):
     _close(st[:, 1].double().sum(0), (x.double() ** 2).sum(0), l2=1e-6, mx=1e-5)
 
 
+@pytest.mark.parametrize("M,C,Cf", [(94080, 64, 256), (1470, 512, 1024), (5880, 96, 1024)])
+def test_rows_op_copy_accumulator_stats(dev, M, C, Cf):
+    """Block entry of the fused-statistics engine: the copy adds the channel sums to the fixed-point accumulators
+    (2^28 scale, 8 replicas) that the first 1x1 conv derives its BN statistics from - no table, no bn_prep launch."""
+    from ddl import ops
+    ext = ops.require_ext()
+    x = _rand(M, C, dev=dev, seed=1)
+    buf = torch.zeros(M, Cf, device=dev)
+    acc = torch.zeros(ext.STAT_REPLICAS, 2, Cf, dtype=torch.int64, device=dev)
+    st = ext.rows_op(0, M, x, None, None, None, buf[:, :C], 1, 1, False, acc_out=acc)
+    assert (st is None or st.numel() == 0) and torch.equal(buf[:, :C], x) and buf[:, C:].abs().sum() == 0
+    assert int(acc[:, :, C:].abs().sum()) == 0
+    got = acc.sum(0).double() / 2.0 ** 28
+    _close(got[0, :C], x.double().sum(0), l2=1e-5, mx=1e-4)
+    _close(got[1, :C], (x.double() ** 2).sum(0), l2=1e-6, mx=1e-5)
+    # integer accumulation: a second launch gives exactly twice the sums, whatever the arrival order
+    first = acc.sum(0).clone()
+    ext.rows_op(0, M, x, None, None, None, buf[:, :C], 1, 1, False, acc_out=acc)
+    assert torch.equal(acc.sum(0), 2 * first)
+
+
 @pytest.mark.parametrize("B,H,C", [(30, 56, 256), (30, 28, 512), (30, 14, 1024)])
 def test_rows_op_pool_fwd_bwd(dev, B, H, C):
     """transition glue: BN+ReLU+2x2 average pool forward (mode 1) and its backward with the ReLU mask, BN scale
