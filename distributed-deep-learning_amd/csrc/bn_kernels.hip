@@ -73,12 +73,28 @@ __global__ void __launch_bounds__(1024) bn_prep_kernel(
     float* __restrict__ chan_mean, float* __restrict__ chan_var, float* __restrict__ chan_rstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ run_mean,
     float* __restrict__ run_var, float* __restrict__ scale, float* __restrict__ shift, int C,
-    float momentum, float eps, int train) {
+    float momentum, float eps, int train, const long long* __restrict__ acc, int acc_ld, int acc_c0, int acc_n,
+    double acc_inv_count) {
   __shared__ double red[PREP_SLICES][2][32];
   __shared__ double s_a[32], s_b[32];
   const int c0 = blockIdx.x * 32;
   const int ch = threadIdx.x & 31;
   const int c = c0 + ch;
+  // channels whose sums still sit in the fixed-point accumulators of the producing dense block (its last slice):
+  // finalised here instead of by a bn_acc_finalize launch in front of this kernel
+  if (train && acc != nullptr && threadIdx.x < 32 && c >= acc_c0 && c < acc_c0 + acc_n && c < C) {
+    long long a1 = 0, a2 = 0;
+    for (int r = 0; r < kStatReplicas; ++r) {
+      a1 += acc[(long)(2 * r) * acc_ld + c];
+      a2 += acc[(long)(2 * r + 1) * acc_ld + c];
+    }
+    const double mean = (double)a1 * acc_inv_count;
+    double var = (double)a2 * acc_inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    chan_mean[c] = (float)mean;
+    chan_var[c] = (float)var;
+    chan_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  }
   const bool is_new = train && partials != nullptr && c0 >= new0 && c0 < new0 + n_new;   // uniform
   if (is_new) {
     reduce_partials32(partials, G, ldp, c0 - new0, s_a, s_b, red);
@@ -115,10 +131,12 @@ __global__ void __launch_bounds__(1024) bn_prep_kernel(
 void launch_bn_prep(const float* partials, int G, int ldp, int new0, int n_new, double count,
                     float* chan_mean, float* chan_var, float* chan_rstd, const float* gamma,
                     const float* beta, float* run_mean, float* run_var, float* scale, float* shift,
-                    int C, float momentum, float eps, bool train, hipStream_t s) {
+                    int C, float momentum, float eps, bool train, const long long* acc, int acc_ld, int acc_c0,
+                    int acc_n, hipStream_t s) {
   hipLaunchKernelGGL(bn_prep_kernel, dim3((C + 31) / 32), dim3(1024), 0, s, partials, G, ldp, new0, n_new,
                      count, chan_mean, chan_var, chan_rstd, gamma, beta, run_mean, run_var, scale, shift,
-                     C, momentum, eps, train ? 1 : 0);
+                     C, momentum, eps, train ? 1 : 0, acc, acc_ld, acc_c0, acc_n,
+                     count > 0 ? 1.0 / (count * kStatScale) : 0.0);
 }
 
 // ---------------------------------------------------------------------------------------------

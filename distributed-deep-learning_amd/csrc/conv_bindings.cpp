@@ -419,8 +419,15 @@ void conv_wgrad_group(int64_t taps, std::vector<at::Tensor> d0, std::vector<at::
 void bn_prep(const OptT& partials, int64_t new0, int64_t n_new, double count, at::Tensor chan_mean,
              at::Tensor chan_var, at::Tensor chan_rstd, const OptT& gamma, const OptT& beta, const OptT& run_mean,
              const OptT& run_var, const OptT& scale, const OptT& shift, int64_t C, double momentum, double eps,
-             bool train) {
+             bool train, const OptT& acc, int64_t acc_c0, int64_t acc_n) {
   ddl::DeviceGuard guard(chan_mean.device());
+  const long long* accp = nullptr; int acc_ld = 0;
+  if (acc.has_value()) {     // channels [acc_c0, acc_c0 + acc_n): statistics from fixed-point accumulators (FusedBn)
+    TORCH_CHECK(train && acc_c0 >= 0 && acc_n > 0 && acc_c0 + acc_n <= C, "bn_prep: accumulator channel range");
+    check_acc(*acc, acc_c0 + acc_n, "acc");
+    accp = reinterpret_cast<const long long*>(acc->data_ptr<int64_t>());
+    acc_ld = (int)acc->stride(1);
+  }
   int G = 0, ldp = 0;
   const float* pp = nullptr;
   if (partials.has_value()) {
@@ -445,7 +452,8 @@ void bn_prep(const OptT& partials, int64_t new0, int64_t n_new, double count, at
   if (g != nullptr) { TORCH_CHECK(sc && sh && scale->numel() >= C && shift->numel() >= C && vec_ptr(beta, "beta", C), "scale/shift/beta"); }
   ddl::launch_bn_prep(pp, G, ldp, (int)new0, (int)n_new, count, chan_mean.data_ptr<float>(),
                       chan_var.data_ptr<float>(), chan_rstd.data_ptr<float>(), g, vec_ptr(beta, "beta", g ? C : 0), rm, rv,
-                      sc, sh, (int)C, (float)momentum, (float)eps, train, cur_stream());
+                      sc, sh, (int)C, (float)momentum, (float)eps, train, accp, acc_ld, (int)acc_c0, (int)acc_n,
+                      cur_stream());
 }
 
 void bn_bwd_prep(const at::Tensor& partials, double count, const at::Tensor& chan_mean, const at::Tensor& chan_rstd,
@@ -558,7 +566,13 @@ void register_conv_ops(pybind11::module_& m) {
       .def(pybind11::init<>())
       .def("flush", &SlabQueue::flush)
       .def("__len__", &SlabQueue::size);
-  m.def("bn_prep", &bn_prep, "finalize channel statistics, derive BN scale/shift, update running stats");
+  m.def("bn_prep", &bn_prep, "finalize channel statistics, derive BN scale/shift, update running stats",
+        pybind11::arg("partials"), pybind11::arg("new0"), pybind11::arg("n_new"), pybind11::arg("count"),
+        pybind11::arg("chan_mean"), pybind11::arg("chan_var"), pybind11::arg("chan_rstd"), pybind11::arg("gamma"),
+        pybind11::arg("beta"), pybind11::arg("run_mean"), pybind11::arg("run_var"), pybind11::arg("scale"),
+        pybind11::arg("shift"), pybind11::arg("C"), pybind11::arg("momentum"), pybind11::arg("eps"),
+        pybind11::arg("train"), pybind11::arg("acc") = c10::nullopt, pybind11::arg("acc_c0") = 0,
+        pybind11::arg("acc_n") = 0);
   m.def("bn_bwd_prep", &bn_bwd_prep, "BN backward per-channel coefficients, dgamma/dbeta");
   m.def("rows_op", &rows_op, "pixel glue ops (copy+stats, pool fwd/bwd, gap bwd, deferred-term apply)",
         pybind11::arg("mode"), pybind11::arg("M"), pybind11::arg("in"), pybind11::arg("x"), pybind11::arg("sc"),

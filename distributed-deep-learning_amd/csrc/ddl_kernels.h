@@ -51,7 +51,8 @@ void launch_slab_reduce_multi(SlabReduceParams& p, hipStream_t s);           // 
 void launch_bn_prep(const float* partials, int G, int ldp, int new0, int n_new, double count,
                     float* chan_mean, float* chan_var, float* chan_rstd, const float* gamma,
                     const float* beta, float* run_mean, float* run_var, float* scale, float* shift,
-                    int C, float momentum, float eps, bool train, hipStream_t s);
+                    int C, float momentum, float eps, bool train, const long long* acc, int acc_ld, int acc_c0,
+                    int acc_n, hipStream_t s);
 void launch_bn_bwd_prep(const float* partials, int G, int ldp, double count, const float* chan_mean,
                         const float* chan_rstd, const float* scale, float* dgamma, float* dbeta, float* k0,
                         float* k1, float* k2, int C, int mode, hipStream_t s);

@@ -66,7 +66,7 @@ std::vector<at::Tensor> stem_fwd(const at::Tensor& x, const at::Tensor& w0, cons
   ddl::launch_bn_prep(pp, train ? G : 0, 64, 0, train ? 64 : 0, (double)M0, st, st + 64, st + 128,
                       gamma.data_ptr<float>(), beta.data_ptr<float>(), run_mean.data_ptr<float>(),
                       run_var.data_ptr<float>(), ss.data_ptr<float>(), ss.data_ptr<float>() + 64, 64,
-                      (float)momentum, (float)eps, train, s);
+                      (float)momentum, (float)eps, train, nullptr, 0, 0, 0, s);
   auto pooled = at::empty({g.B, g.H1, g.W1, 64}, f32);
   at::Tensor idx;
   uint8_t* ip = nullptr;

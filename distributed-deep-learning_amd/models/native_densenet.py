@@ -95,7 +95,11 @@ class _BlockFn(torch.autograd.Function):
                 ext.conv_fwd_fused(h[l], acc_h[:, :, hs], 0, lay.g2, lay.b2, lay.rm2, lay.rv2, bn2[l, 3], bn2[l, 4],
                                    bn2[l, 0], bn2[l, 1], bn2[l, 2], float(M), BN_MOMENTUM, BN_EPS, M, H, W, 9,
                                    lay.w2, buf2d[:, C:C + GROWTH], acc_b[:, :, C:C + GROWTH], 0, bf)
-            ext.bn_acc_finalize(acc_b, Cf - GROWTH, GROWTH, float(M), BN_EPS, stats[0], stats[1], stats[2])
+            if unit.defer_finalize:     # the following transition / head finalises the last slice in its bn_prep
+                unit.pending_acc = (acc_b, Cf - GROWTH, GROWTH)
+            else:
+                unit.pending_acc = None
+                ext.bn_acc_finalize(acc_b, Cf - GROWTH, GROWTH, float(M), BN_EPS, stats[0], stats[1], stats[2])
             unit.out_stats = stats
             ctx.unit = unit
             ctx.geom = (B, H, W, C0)
@@ -119,6 +123,7 @@ class _BlockFn(torch.autograd.Function):
             ext.bn_prep(part, new0, n_new, float(M), stats[0], stats[1], stats[2], None, None, None, None,
                         None, None, Cf, BN_MOMENTUM, BN_EPS, True)
         unit.out_stats = stats if train else None
+        unit.pending_acc = None
         ctx.unit = unit
         ctx.geom = (B, H, W, C0)
         ctx.save_for_backward(buf, stats, sc1, sh1, bn2, h)
@@ -353,6 +358,8 @@ class BlockUnit:
         self.c_in, self.c_out = c0 + GROWTH * self.l0, c0 + GROWTH * self.l1
         self.layers: List[_Layer] = []
         self.out_stats: Optional[torch.Tensor] = None
+        self.pending_acc = None             # (accumulators, first channel, count) the consumer still has to finalise
+        self.defer_finalize = False         # set by the stage: the next unit is a transition / head of this stage
         self.param_names: List[str] = []
 
     def bind(self) -> None:
@@ -376,6 +383,8 @@ class BlockUnit:
 
     def __call__(self, x: torch.Tensor, in_stats) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         y = _BlockFn.apply(x, self.stage.anchor, self)
+        if self.pending_acc is not None:
+            return y, (self.out_stats, self.pending_acc)
         return y, self.out_stats
 
 
@@ -402,12 +411,17 @@ class _TransitionFn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=buf.device)
         buf = buf.contiguous()
         buf2d = buf.view(M, C)
+        pend = {}
+        if isinstance(in_stats, tuple):      # a dense block that left its last slice in the accumulators
+            in_stats, (pacc, pc0, pn) = in_stats
+            if train:
+                pend = dict(acc=pacc, acc_c0=pc0, acc_n=pn)
         if train and in_stats is None:
             in_stats = _input_stats(ext, buf2d, M, C, H, W)
         stats = in_stats if train else torch.empty(3, C, **f32)
         ss = torch.empty(2, C, **f32)
         ext.bn_prep(None, 0, 0, float(M), stats[0], stats[1], stats[2], unit.g, unit.b, unit.rm, unit.rv,
-                    ss[0], ss[1], C, BN_MOMENTUM, BN_EPS, train)
+                    ss[0], ss[1], C, BN_MOMENTUM, BN_EPS, train, **pend)
         pooled = torch.empty(Mp, C, **f32)
         ext.rows_op(1, Mp, pooled, buf2d, ss[0], ss[1], pooled, H, W, False)
         y = torch.empty(B, H // 2, W // 2, Co, **f32)
@@ -474,12 +488,17 @@ class _HeadFn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=buf.device)
         buf = buf.contiguous()
         buf2d = buf.view(M, C)
+        pend = {}
+        if isinstance(in_stats, tuple):      # a dense block that left its last slice in the accumulators
+            in_stats, (pacc, pc0, pn) = in_stats
+            if train:
+                pend = dict(acc=pacc, acc_c0=pc0, acc_n=pn)
         if train and in_stats is None:
             in_stats = _input_stats(ext, buf2d, M, C, H, W)
         stats = in_stats if train else torch.empty(3, C, **f32)
         ss = torch.empty(2, C, **f32)
         ext.bn_prep(None, 0, 0, float(M), stats[0], stats[1], stats[2], unit.g, unit.b, unit.rm, unit.rv,
-                    ss[0], ss[1], C, BN_MOMENTUM, BN_EPS, train)
+                    ss[0], ss[1], C, BN_MOMENTUM, BN_EPS, train, **pend)
         pooled = ext.bnrelu_gap_fwd(buf2d, B, H * W, ss[0], ss[1])
         logits = ext.linear_fwd(pooled, unit.cw, unit.cb)
         ctx.unit = unit
@@ -654,6 +673,9 @@ class NativeDenseNetStage(nn.Module):
                 self.unit_objs.append(TransitionUnit(self, u))
             else:
                 self.unit_objs.append(HeadUnit(self))
+        for a, b in zip(self.unit_objs[:-1], self.unit_objs[1:]):
+            if isinstance(a, BlockUnit) and isinstance(b, (TransitionUnit, HeadUnit)):
+                a.defer_finalize = True         # b's bn_prep finalises a's last channel slice (one launch fewer)
         for u in self.unit_objs:
             u.bind()
 
