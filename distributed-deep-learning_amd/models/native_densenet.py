@@ -158,6 +158,12 @@ class _BlockFn(torch.autograd.Function):
         acc = zero[:8 * n_acc].view(torch.int64).view(L, R, 2, MID + Cf) if n_acc else None
         fz = zero[8 * n_acc:].view(torch.float32)
         nq, np_ = fz[:Cf], fz[Cf:2 * Cf]
+        # The transition / head behind this block left its own BN backward as (sc*g in dBuf, k1, k2): exactly the
+        # form of the deferred terms, so its k1 / k2 vectors BECOME nq / np (no dX = dBuf + k1*x + k2 pass over the
+        # whole block buffer: 47 us behind block 1 at batch 30).
+        pend = unit.stage.take_pending_affine(unit)
+        if pend is not None:
+            nq, np_ = pend[0], pend[1]
         tickets = fz[2 * Cf:].view(torch.int32).view(L, 2, 32) if n_acc else None
         ones = unit.stage.ones
         # Weight gradients feed nothing downstream, so they run on a side stream beside the
@@ -452,7 +458,10 @@ class _TransitionFn(torch.autograd.Function):
         st = ext.rows_op(2, M, dpool, buf2d, ss[0], ss[1], d2d, H, W, True)
         k = torch.empty(3, C, **f32)
         ext.bn_bwd_prep(st, float(M), stats[0], stats[2], ss[0], unit.gg, unit.gb, k[0], k[1], k[2], C, 0)
-        ext.rows_op(4, M, d2d, buf2d, k[1], k[2], d2d, H, W, False)     # dX = sc*g + k1*x + k2
+        if unit.defer_affine:       # the dense block in front adopts k1 / k2 as its deferred terms
+            unit.stage.set_pending_affine(unit, k[1], k[2])
+        else:
+            ext.rows_op(4, M, d2d, buf2d, k[1], k[2], d2d, H, W, False)     # dX = sc*g + k1*x + k2
         unit.stage._unit_grads_ready(unit)
         unit.stage._owned_grad_ptr = dbuf.data_ptr()       # fresh tensor, single consumer: may be updated in place
         return dbuf, None, None, None
@@ -461,6 +470,7 @@ class _TransitionFn(torch.autograd.Function):
 class TransitionUnit:
     def __init__(self, stage: "NativeDenseNetStage", name: str) -> None:
         self.stage, self.name = stage, name
+        self.defer_affine = False           # set by the stage: the unit in front is a dense block of this stage
         self.param_names: List[str] = []
 
     def bind(self) -> None:
@@ -521,7 +531,10 @@ class _HeadFn(torch.autograd.Function):
         st = ext.rows_op(3, M, dpooled, buf2d, ss[0], ss[1], d2d, H, W, True)
         k = torch.empty(3, C, **f32)
         ext.bn_bwd_prep(st, float(M), stats[0], stats[2], ss[0], unit.gg, unit.gb, k[0], k[1], k[2], C, 0)
-        ext.rows_op(4, M, d2d, buf2d, k[1], k[2], d2d, H, W, False)
+        if unit.defer_affine:
+            unit.stage.set_pending_affine(unit, k[1], k[2])
+        else:
+            ext.rows_op(4, M, d2d, buf2d, k[1], k[2], d2d, H, W, False)
         unit.stage._unit_grads_ready(unit)
         unit.stage._owned_grad_ptr = dbuf.data_ptr()
         return dbuf, None, None, None
@@ -530,6 +543,7 @@ class _HeadFn(torch.autograd.Function):
 class HeadUnit:
     def __init__(self, stage: "NativeDenseNetStage") -> None:
         self.stage, self.name = stage, "head"
+        self.defer_affine = False
         self.param_names: List[str] = []
 
     def bind(self) -> None:
@@ -676,6 +690,9 @@ class NativeDenseNetStage(nn.Module):
         for a, b in zip(self.unit_objs[:-1], self.unit_objs[1:]):
             if isinstance(a, BlockUnit) and isinstance(b, (TransitionUnit, HeadUnit)):
                 a.defer_finalize = True         # b's bn_prep finalises a's last channel slice (one launch fewer)
+                b.defer_affine = os.environ.get("DDL_DEFER_AFFINE", "1") == "1"   # a adopts b's BN-backward k1 / k2
+                a.next_unit = b
+        self._pending_affine = None
         for u in self.unit_objs:
             u.bind()
 
@@ -737,6 +754,23 @@ class NativeDenseNetStage(nn.Module):
 
     def bv(self, fqn: str) -> torch.Tensor:
         return self._buffers_by_name[fqn]
+
+    # ---- BN backward of a transition / head handed to the dense block in front of it ---------------------------
+    def set_pending_affine(self, producer, k1: torch.Tensor, k2: torch.Tensor) -> None:
+        if self._pending_affine is not None:
+            raise RuntimeError("a deferred BN-backward term was never consumed (backward of a dense block skipped?)")
+        self._pending_affine = (producer, k1, k2)
+
+    def take_pending_affine(self, block):
+        """(k1, k2) left by the unit behind ``block`` in this backward pass, or None.  The hand-off is by unit
+        adjacency: the gradient that reaches ``block`` IS the producer's returned tensor (or a copy of it) - the
+        block's output has no other consumer inside a stage."""
+        p, self._pending_affine = self._pending_affine, None
+        if p is None:
+            return None
+        if p[0] is not getattr(block, "next_unit", None):
+            raise RuntimeError(f"deferred BN-backward term of {p[0].name} reached {block.name}")
+        return p[1], p[2]
 
     def wgrad_group_size(self, M: int) -> int:
         """Dense layers whose weight gradients share one launch (``_backward_grouped``).  ``DDL_WGRAD_GROUP``: an
@@ -801,6 +835,7 @@ class NativeDenseNetStage(nn.Module):
         ``y.backward(y_leaf.grad)`` for the cuts in reverse order runs the earlier phases - each call
         can be its own hipGraph, with that phase's gradient buckets handed to RCCL in between."""
         stats, cuts = None, []
+        self._pending_affine = None
         for i, u in enumerate(self.unit_objs):
             if i in self.phase_starts:
                 leaf = x.detach().requires_grad_(True)
@@ -822,6 +857,7 @@ class NativeDenseNetStage(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         stats = None
+        self._pending_affine = None          # a backward pass that died half-way must not leak into the next one
         for u in self.unit_objs:
             x, stats = u(x, stats)
         if self.training:
