@@ -368,6 +368,32 @@ def test_block_transition_block(dev):
     _compare_unit(dev, ("denseblock2", "transition2", "denseblock3"), (2, 128, 8, 8), tol=3e-2, global_l2=True)
 
 
+def test_bn_backward_handoff_equals_the_explicit_pass(dev, monkeypatch):
+    """A transition / the head leaves its BN backward `k1*x + k2` to the dense block in front of it (the vectors become
+    the block's deferred terms) instead of a pass over the whole block buffer.  Same forward, same masks - only the
+    order of a few additions differs - so the gradients must agree far below the tolerance of the oracle tests."""
+    units = ("denseblock2", "transition2", "denseblock3", "transition3", "denseblock4", "head")
+    ref = _ref_stage(units, dev)
+    stages = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DDL_DEFER_AFFINE", flag)
+        stages[flag] = _native_from(ref, units, dev)
+        stages[flag].train()
+    assert stages["1"].unit_objs[1].defer_affine and not stages["0"].unit_objs[1].defer_affine
+    x = _rand(3, 8, 8, 128, dev=dev, seed=5)
+    gy = _rand(3, 5, dev=dev, seed=6)
+    grads = {}
+    for flag, nat in stages.items():
+        xn = x.clone().requires_grad_(True)
+        nat.arena.zero_grad()
+        nat(xn).backward(gy)
+        grads[flag] = [xn.grad.double().flatten()] + [p.grad.double().flatten() for _, p in nat.named_parameters()]
+    a, b = torch.cat(grads["1"]), torch.cat(grads["0"])
+    assert float((a - b).norm() / b.norm()) < 2e-6
+    for ga, gb in zip(grads["1"], grads["0"]):
+        assert float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max().clamp_min(1e-6)) + 1e-9
+
+
 def test_partial_dense_blocks_fwd_bwd(dev):
     """A pipeline stage that starts and ends INSIDE dense blocks (layers 5-12 of block 2, transition 2, layers 1-8 of
     block 3): the native units take the concatenated prefix as their input like a block takes its own."""

@@ -105,3 +105,31 @@ def test_native_png_loader_feeds_the_gpu(dev, tmp_path):
     res, _ = data.build_loaders(cfg, device=dev)
     assert isinstance(res, data.ResidentLoader) and res.images.is_cuda
     assert all(torch.equal(res.images[i].cpu(), ds[i][0]) for i in range(len(ds)))
+
+
+def test_cross_entropy_backward_shortcut_is_bit_identical(dev):
+    """`ops.cross_entropy_backward` hands the fused kernel's d(loss)/d(logits) straight to `logits.backward` (no
+    autograd node for the loss: two launches fewer in the captured step) - same loss, predictions and gradients as
+    `cross_entropy_with_preds(...)[0].backward()`, bit for bit; on the CPU it is the plain autograd path."""
+    from ddl import ops
+    torch.manual_seed(0)
+    w = torch.randn(7, 5, device=dev)
+    x = torch.randn(30, 7, device=dev)
+    y = torch.randint(0, 5, (30,), device=dev)
+    res = {}
+    for name in ("shortcut", "autograd"):
+        wp = w.clone().requires_grad_(True)
+        logits = x @ wp
+        if name == "shortcut":
+            loss, preds = ops.cross_entropy_backward(logits, y)
+        else:
+            loss, preds = ops.cross_entropy_with_preds(logits, y)
+            loss.backward()
+        res[name] = (loss.detach().clone(), preds.clone(), wp.grad.clone())
+    for a, b in zip(res["shortcut"], res["autograd"]):
+        assert torch.equal(a, b)
+    assert not res["shortcut"][0].requires_grad
+    wc = w.cpu().requires_grad_(True)
+    loss, preds = ops.cross_entropy_backward(x.cpu() @ wc, y.cpu())
+    torch.testing.assert_close(wc.grad, res["autograd"][2].cpu(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(preds, res["autograd"][1].cpu())
