@@ -39,6 +39,21 @@ std::vector<at::Tensor> ce_fwd_bwd(const at::Tensor& logits, const at::Tensor& t
   return {loss, dlogits, preds};
 }
 
+// dst_a <- src_a, dst_b <- src_b in one launch (the captured step's static inputs); contiguous same-shape pairs,
+// the first one a multiple of 16 bytes at 16-byte aligned addresses
+void copy_pair(at::Tensor dst_a, const at::Tensor& src_a, at::Tensor dst_b, const at::Tensor& src_b) {
+  for (const at::Tensor* t : std::initializer_list<const at::Tensor*>{&dst_a, &src_a, &dst_b, &src_b}) {
+    CHECK_DEV(*t); CHECK_CONTIG(*t);
+  }
+  TORCH_CHECK(dst_a.scalar_type() == src_a.scalar_type() && dst_a.sizes() == src_a.sizes() &&
+                  dst_b.scalar_type() == src_b.scalar_type() && dst_b.sizes() == src_b.sizes(), "copy_pair: shape / dtype");
+  const int64_t na = dst_a.numel() * dst_a.element_size(), nb = dst_b.numel() * dst_b.element_size();
+  TORCH_CHECK(na % 16 == 0 && reinterpret_cast<uintptr_t>(dst_a.data_ptr()) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(src_a.data_ptr()) % 16 == 0, "copy_pair: 16-byte granularity for the first pair");
+  ddl::DeviceGuard guard(dst_a.device());
+  ddl::launch_copy_pair(src_a.data_ptr(), dst_a.data_ptr(), na, src_b.data_ptr(), dst_b.data_ptr(), nb, cur_stream());
+}
+
 void adam_step(at::Tensor p, at::Tensor g, at::Tensor m, at::Tensor v, at::Tensor step_t, at::Tensor aux,
                double lr, double b1, double b2, double eps, double wd, bool zero_grad,
                std::vector<int64_t> starts, std::vector<int64_t> ends) {
@@ -74,6 +89,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("normalize_u8", &normalize_u8, "uint8 NCHW -> fp32/255 (NHWC or NCHW)");
   m.def("ce_fwd_bwd", &ce_fwd_bwd, "fused softmax+CE loss, dlogits, argmax");
   m.def("adam_step", &adam_step, "flat fused Adam (+zero_grad)");
+  m.def("copy_pair", &copy_pair, "two device-to-device copies in one launch");
   register_conv_ops(m);
   register_stem_ops(m);
   register_reducer(m);

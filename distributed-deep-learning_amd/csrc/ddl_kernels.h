@@ -21,6 +21,8 @@ namespace ddl {
 void launch_normalize_u8(const uint8_t* in, float* out, int B, int C, int H, int W, bool nhwc,
                          hipStream_t s);
 // fused softmax + cross-entropy (mean) + d(loss)/d(logits) + argmax; logits [B,C] row-major.
+void launch_copy_pair(const void* a_src, void* a_dst, long a_bytes, const void* b_src, void* b_dst, long b_bytes,
+                      hipStream_t s);
 void launch_ce_fwd_bwd(const float* logits, const int64_t* targets, float* loss /*[1], zeroed here*/,
                        float* dlogits, int64_t* preds, int B, int C, hipStream_t s);
 // flat Adam over [start,end) of four parallel arrays; step counter lives on the device.

@@ -89,6 +89,31 @@ __global__ void __launch_bounds__(1024) ce_fwd_bwd_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// copy_pair: the step's two input copies (image batch + labels into the captured graph's static buffers) as ONE
+// launch - every eager operation between two graph launches costs a queue round trip at the step boundary.
+// a: n16 16-byte chunks (grid-stride), b: nb bytes (first workgroup).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) copy_pair_kernel(const uint4* __restrict__ a_src, uint4* __restrict__ a_dst,
+                                                        long n16, const unsigned char* __restrict__ b_src,
+                                                        unsigned char* __restrict__ b_dst, long nb) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n16; i += stride) a_dst[i] = a_src[i];
+  if (blockIdx.x == 0)
+    for (long i = threadIdx.x; i < nb; i += 256) b_dst[i] = b_src[i];
+}
+
+void launch_copy_pair(const void* a_src, void* a_dst, long a_bytes, const void* b_src, void* b_dst, long b_bytes,
+                      hipStream_t s) {
+  const long n16 = a_bytes / 16;
+  long grid = (n16 + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(copy_pair_kernel, dim3((unsigned)grid), dim3(256), 0, s, reinterpret_cast<const uint4*>(a_src),
+                     reinterpret_cast<uint4*>(a_dst), n16, reinterpret_cast<const unsigned char*>(b_src),
+                     reinterpret_cast<unsigned char*>(b_dst), b_bytes);
+}
+
 void launch_ce_fwd_bwd(const float* logits, const int64_t* targets, float* loss, float* dlogits,
                        int64_t* preds, int B, int C, hipStream_t s) {
   hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(1), dim3(1024), 0, s, logits, targets, loss, dlogits,

@@ -92,6 +92,19 @@ def cross_entropy_with_preds(logits: torch.Tensor, targets: torch.Tensor) -> Tup
     return F.cross_entropy(logits, targets), logits.detach().argmax(dim=1)
 
 
+def copy_inputs(dst_x: torch.Tensor, x: torch.Tensor, dst_y: torch.Tensor, y: torch.Tensor) -> None:
+    """``dst_x.copy_(x); dst_y.copy_(y)`` - on the GPU as ONE launch when the layout allows it (the two input copies
+    in front of a graph replay; each eager operation between two graph launches is a queue round trip)."""
+    if (os.environ.get("DDL_COPY_PAIR", "1") == "1" and x.is_cuda and y.is_cuda and dst_x.is_cuda and have_ext()
+            and x.dtype == dst_x.dtype and y.dtype == dst_y.dtype and x.shape == dst_x.shape and y.shape == dst_y.shape
+            and x.is_contiguous() and y.is_contiguous() and dst_x.is_contiguous() and dst_y.is_contiguous()
+            and (x.numel() * x.element_size()) % 16 == 0 and x.data_ptr() % 16 == 0 and dst_x.data_ptr() % 16 == 0):
+        require_ext().copy_pair(dst_x, x, dst_y, y)
+        return
+    dst_x.copy_(x, non_blocking=True)
+    dst_y.copy_(y, non_blocking=True)
+
+
 def cross_entropy_backward(logits: torch.Tensor, targets: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """``loss = cross_entropy(logits, targets); loss.backward()`` in one go, returning ``(loss.detach(), preds)``.
     On the GPU the fused kernel's d(loss)/d(logits) is handed straight to ``logits.backward`` - no autograd node for

@@ -124,8 +124,7 @@ class GraphedTrainStep:
 
     def _replay(self, c: _Captured, x, y):
         dp = self.dp
-        c.x.copy_(x, non_blocking=True)
-        c.y.copy_(y, non_blocking=True)
+        ops.copy_inputs(c.x, x, c.y, y)
         if dp is not None:
             dp.pre_forward(training=True)
         if self.distributed:

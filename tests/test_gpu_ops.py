@@ -133,3 +133,24 @@ def test_cross_entropy_backward_shortcut_is_bit_identical(dev):
     loss, preds = ops.cross_entropy_backward(x.cpu() @ wc, y.cpu())
     torch.testing.assert_close(wc.grad, res["autograd"][2].cpu(), rtol=1e-5, atol=1e-6)
     assert torch.equal(preds, res["autograd"][1].cpu())
+
+
+def test_copy_inputs_single_launch(dev):
+    """`ops.copy_inputs`: the step's image + label copies as one launch; falls back to two `copy_` calls when the
+    layout does not allow 16-byte chunks."""
+    from ddl import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randint(0, 256, (30, 3, 224, 224), dtype=torch.uint8, generator=g).to(dev)
+    y = torch.randint(0, 5, (30,), generator=g).to(dev)
+    dx, dy = torch.zeros_like(x), torch.zeros_like(y)
+    ops.copy_inputs(dx, x, dy, y)
+    assert torch.equal(dx, x) and torch.equal(dy, y)
+    x2 = torch.randint(0, 256, (3, 3, 5, 7), dtype=torch.uint8, generator=g).to(dev)      # 315 bytes: fallback path
+    y2 = torch.randint(0, 5, (3,), generator=g).to(dev)
+    dx2, dy2 = torch.zeros_like(x2), torch.zeros_like(y2)
+    ops.copy_inputs(dx2, x2, dy2, y2)
+    assert torch.equal(dx2, x2) and torch.equal(dy2, y2)
+    xs = x[:, :, ::2]                                                                    # non-contiguous source
+    dxs = torch.zeros_like(xs)
+    ops.copy_inputs(dxs, xs, dy, y)
+    assert torch.equal(dxs, xs)
