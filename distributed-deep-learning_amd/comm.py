@@ -298,7 +298,9 @@ def reduce_scatter_into(shard: torch.Tensor, full: torch.Tensor, op: str = "sum"
 
 
 def barrier(group=None) -> None:
-    if is_dist():
+    # a group of one has nothing to wait for: no RCCL communicator is created just for it (its version banner goes
+    # to stdout, next to bench.py's JSON line) - unless the rehearsal switch asks for every collective
+    if is_dist() and (get_world_size(group) > 1 or force_collectives()):
         if backend_of(group) == "nccl":
             dist.barrier(group=group, device_ids=[torch.cuda.current_device()])
         else:
