@@ -84,6 +84,13 @@ def main() -> None:
                                                       "4 extra steps BEHIND the timed region (ddl/utils/trace.py)")
     a = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON of rank 0.  Native libraries write to file descriptor 1 as well (RCCL
+    # prints a five-line version banner from every rank when its first communicator comes up), so fd 1 is pointed at
+    # stderr for the whole run and the JSON goes to a private duplicate of the original stdout.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     from ddl import comm
     from ddl.config import TrainConfig
     from ddl.models.densenet import default_split_points
@@ -290,7 +297,7 @@ def main() -> None:
 
     def emit() -> None:
         if ctx.rank == 0:
-            print(json.dumps(out), flush=True)
+            print(json.dumps(out), file=json_out, flush=True)
 
     # The headline is measured.  Everything behind this point is tuning data (multi-rank runs; `--ab on` to rehearse
     # with one rank): a hang or crash in it - a collective that never completes on a first multi-GPU run - must not
