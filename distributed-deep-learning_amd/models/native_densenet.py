@@ -792,9 +792,20 @@ class NativeDenseNetStage(nn.Module):
     # stream only, and joined into the origin directly.  ``fork`` / ``join`` enforce it; ``assert_joined`` is
     # called by the capture code before a capture ends.
     def fork(self, origin: "torch.cuda.Stream") -> "torch.cuda.Stream":
-        if origin == self.side_stream or self._fork_origin is not None:
+        if self._fork_origin is not None:
             raise RuntimeError("nested stream fork: the weight-gradient side stream must be forked from the origin "
                                "stream and joined into it directly (a nested fork crashes hipStreamEndCapture)")
+        if origin == self.side_stream:
+            # torch hands streams out of a pool of 32, round-robin: every 32nd stream drawn in a process is the one
+            # torch.cuda.graph captures on (its class-level default capture stream), so a stage built late in a
+            # long-lived process can find its side stream IS the stream it runs on.  Draw another one.
+            for _ in range(64):
+                s = torch.cuda.Stream(origin.device)
+                if s != origin:
+                    self.side_stream = s
+                    break
+            else:
+                raise RuntimeError("no stream distinct from the origin stream could be drawn from the stream pool")
         self._fork_origin = origin
         return self.side_stream
 

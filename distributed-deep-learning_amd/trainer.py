@@ -125,7 +125,8 @@ class SingleStrategy(Strategy):
         # zero_grad -> forward -> fused CE -> backward -> fused Adam (reference: single.py:136-154),
         # replayed as one hipGraph launch after two eager warm-up steps
         self._step = GraphedTrainStep(self.model, self.optimizer, None, self.profiler,
-                                      enabled=cfg.hip_graph and self.device.type == "cuda")
+                                      enabled=cfg.hip_graph and self.device.type == "cuda",
+                                      fuse_zero_grad=not cfg.log_gradients)
         self._eval = GraphedEvalStep(self.model, enabled=cfg.hip_graph and self.device.type == "cuda")
 
     def train_step(self, x, y, batch_size):
@@ -153,7 +154,8 @@ class DDPStrategy(Strategy):
         self.dp_rank, self.dp_size = self.dp.rank, self.dp.world
         self.is_logger = ctx.rank == 0
         self._step = GraphedTrainStep(self.model, self.optimizer, self.dp, self.profiler,
-                                      enabled=cfg.hip_graph and self.device.type == "cuda")
+                                      enabled=cfg.hip_graph and self.device.type == "cuda",
+                                      fuse_zero_grad=not cfg.log_gradients)
         self._eval = GraphedEvalStep(self.model, enabled=cfg.hip_graph and self.device.type == "cuda")
 
     def _native_kw(self, cfg, world):

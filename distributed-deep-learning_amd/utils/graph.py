@@ -37,20 +37,45 @@ class _Captured:
     __slots__ = ("graph", "x", "y", "loss", "out", "preds", "tail_graphs", "phase_segments")
 
 
+def _step_takes_zero_grad(optimizer) -> bool:
+    import inspect
+    try:
+        return "zero_grad" in inspect.signature(optimizer.step).parameters
+    except (TypeError, ValueError):
+        return False
+
+
 class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, optimizer, dp=None, profiler=None, warmup: int = 2,
-                 enabled: bool = True) -> None:
+                 enabled: bool = True, fuse_zero_grad: bool = True) -> None:
         self.model, self.optimizer, self.dp, self.profiler = model, optimizer, dp, profiler
         self.warmup = warmup
         self.enabled = enabled
+        # reference order: zero_grad -> forward -> backward -> step (single.py:137-154).  The fused Adam kernel can
+        # clear the gradient arena in the pass that consumed it, which makes the 28 MB memset at the head of every
+        # step redundant; off (explicit memset, gradients readable after the step) for --log-gradients
+        self.fuse_zero_grad = (bool(fuse_zero_grad) and _step_takes_zero_grad(optimizer)
+                               and getattr(optimizer, "shard", None) is None)      # ZeRO-1 steps touch their shard only
+        self._grads_clean = False        # True once a fused step has left the arena zeroed
         self.distributed = dp is not None and not dp.single
         self._seen: Dict[Tuple, int] = {}
         self._graphs: Dict[Tuple, _Captured] = {}
         self._pool = None
 
     # ---- the step body ----------------------------------------------------------------------
+    def _zero_grad(self) -> None:
+        if not (self.fuse_zero_grad and self._grads_clean):
+            self.optimizer.zero_grad()
+
+    def _opt_step(self) -> None:
+        if self.fuse_zero_grad:
+            self.optimizer.step(zero_grad=True)
+            self._grads_clean = True
+        else:
+            self.optimizer.step()
+
     def _fwd_bwd(self, x, y, after_forward=None):
-        self.optimizer.zero_grad()
+        self._zero_grad()
         out = self.model(x)
         if after_forward is not None:
             after_forward()
@@ -68,7 +93,7 @@ class GraphedTrainStep:
             dp.finish_grad_sync()
             if prof:
                 prof.end(tok)
-        self.optimizer.step()
+        self._opt_step()
         if dp is not None:
             dp.post_step()
         return res
@@ -102,11 +127,11 @@ class GraphedTrainStep:
             with torch.cuda.graph(c.graph, **mode):
                 c.loss, c.out, c.preds = self._fwd_bwd(c.x, c.y)
                 if not self.distributed:
-                    self.optimizer.step()
+                    self._opt_step()
                 self._check_joined()
         else:
             with torch.cuda.graph(c.graph, **mode):
-                self.optimizer.zero_grad()
+                self._zero_grad()
                 out, cuts = self.model.forward_phased(c.x)
                 c.loss, c.preds = ops.cross_entropy_backward(out, c.y)
                 c.out = out.detach()
@@ -145,7 +170,7 @@ class GraphedTrainStep:
             if self.profiler:
                 self.profiler.end(tok)
             with trace_range("adam"):
-                self.optimizer.step()
+                self._opt_step()
             dp.post_step()
         elif hasattr(self.optimizer, "_host_step"):
             self.optimizer._host_step += 1

@@ -221,8 +221,15 @@ def test_stream_fork_discipline_is_enforced():
         nat.fork(main)                                               # second fork while one is open
     with pytest.raises(RuntimeError, match="not joined"):
         nat.assert_joined()                                          # what the capture code calls before capture_end
+    # no fork open and the origin IS the side stream: a stream-pool collision (torch draws streams round-robin from
+    # a pool of 32, so a stage built late in a process can hold the stream torch.cuda.graph captures on), not a
+    # nested fork - the stage draws another side stream
+    redrawn = nat.fork(side)
+    assert redrawn != side and nat.side_stream == redrawn
     with pytest.raises(RuntimeError, match="nested stream fork"):
-        nat.fork(side)                                               # forking FROM the side stream
+        nat.fork(redrawn)                                            # ... but never while a fork is open
+    nat.join(side, redrawn)
+    side = redrawn
     nat.fork(main)
     with pytest.raises(RuntimeError, match="does not match"):
         nat.join(torch.cuda.Stream(dev), side)                       # joining into a stream that is not the origin

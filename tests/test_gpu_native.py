@@ -578,6 +578,34 @@ def test_graphed_eval_step_matches_eager(dev):
     assert step(xs[0]).shape == (4, 5) and len(step._graphs) == 1      # training mode: never replayed
 
 
+def test_training_step_captures_when_the_side_stream_is_the_capture_stream(dev):
+    """Streams come round-robin out of a pool of 32, and torch.cuda.graph captures on one class-level stream: the
+    stage whose side stream is that very stream (every 32nd stream drawn in a process - it hit the test suite as
+    its stream count grew) must still capture and give the same losses as any other stage."""
+    from ddl import comm
+    from ddl.config import TrainConfig
+    from ddl.models.densenet import UNIT_NAMES
+    from ddl.trainer import SingleStrategy
+    ref = _ref_stage(UNIT_NAMES, dev)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randint(0, 256, (3, 3, 64, 64), dtype=torch.uint8, generator=g).to(dev)
+    y = torch.randint(0, 5, (3,), generator=g).to(dev)
+    if torch.cuda.graph.default_capture_stream is None:
+        torch.cuda.graph.default_capture_stream = torch.cuda.Stream()
+    runs = []
+    for collide in (False, True):
+        strat = SingleStrategy(TrainConfig(strategy="single", batch_size=3), comm.CommContext(0, 1, 0, dev, "none"))
+        strat.model.import_state_dict(ref.state_dict())
+        if collide:
+            strat.model.side_stream = torch.cuda.graph.default_capture_stream
+        elif strat.model.side_stream == torch.cuda.graph.default_capture_stream:
+            strat.model.side_stream = torch.cuda.Stream(dev)
+        runs.append(torch.stack([strat.train_step(x, y, 3)[0].clone() for _ in range(5)]).cpu())
+        if collide:
+            assert strat.model.side_stream != torch.cuda.graph.default_capture_stream      # redrawn at the capture
+    torch.testing.assert_close(runs[1], runs[0], rtol=0, atol=0)
+
+
 @pytest.mark.parametrize("B,S", [(1, 224), (5, 96), (33, 64), (7, 160), (2, 32)])
 def test_odd_batches_and_image_sizes_train(dev, B, S):
     """Whole-model steps on shapes that leave every tile ragged (1 image, 33 images, 96/160/32-pixel inputs: 5x5, 3x3,
