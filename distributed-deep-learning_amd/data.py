@@ -33,6 +33,8 @@ import numpy as np
 import torch
 from torch.utils.data import DataLoader, Dataset, Sampler
 
+from .utils.streams import new_stream
+
 
 class Normalize:
     """uint8 -> float32 in [0,1] (reference: single.py:38-42; no mean/std, no augmentation)."""
@@ -250,7 +252,7 @@ class DevicePrefetcher:
     def __init__(self, loader, device, needs_input: bool = True, needs_target: bool = True) -> None:
         self.loader, self.device = loader, torch.device(device)
         self.needs_input, self.needs_target = needs_input, needs_target
-        self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        self.stream = new_stream(self.device) if self.device.type == "cuda" else None
 
     def __len__(self) -> int:
         return len(self.loader)

@@ -44,6 +44,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..utils.arena import FlatArena, FlatBuffers, reverse_named_parameters
+from ..utils.streams import new_stream
 from .densenet import (BLOCK_CONFIG, BN_SIZE, GROWTH, UNIT_NAMES, DenseNetStage, block_channels, parse_unit)
 
 BN_MOMENTUM = 0.1
@@ -669,7 +670,7 @@ class NativeDenseNetStage(nn.Module):
         self.param_index: Dict[str, int] = {n: i for i, n in enumerate(self.arena.names)}
         self._buffers_by_name = dict(self.named_buffers())
         self.anchor = torch.zeros(1, device=device, requires_grad=True)   # keeps every unit in the graph
-        self.side_stream = torch.cuda.Stream(device)
+        self.side_stream = new_stream(device)
         self.overlap_wgrad = True
         self._wgrad_group = os.environ.get("DDL_WGRAD_GROUP", "auto")
         self.tail_prep = os.environ.get("DDL_TAIL_PREP", "1") == "1"      # csrc/conv_params.h TailPrep (grouped backward)
@@ -799,13 +800,7 @@ class NativeDenseNetStage(nn.Module):
             # torch hands streams out of a pool of 32, round-robin: every 32nd stream drawn in a process is the one
             # torch.cuda.graph captures on (its class-level default capture stream), so a stage built late in a
             # long-lived process can find its side stream IS the stream it runs on.  Draw another one.
-            for _ in range(64):
-                s = torch.cuda.Stream(origin.device)
-                if s != origin:
-                    self.side_stream = s
-                    break
-            else:
-                raise RuntimeError("no stream distinct from the origin stream could be drawn from the stream pool")
+            self.side_stream = new_stream(origin.device, avoid=[origin])
         self._fork_origin = origin
         return self.side_stream
 

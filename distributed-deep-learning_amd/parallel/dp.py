@@ -46,6 +46,7 @@ import torch.distributed as dist
 
 from .. import comm, ops
 from ..utils.arena import FlatArena, FlatBuffers, reverse_named_parameters
+from ..utils.streams import new_stream
 
 
 class DataParallelEngine:
@@ -82,7 +83,8 @@ class DataParallelEngine:
         self.buffers = getattr(module, "flat_buffers", None) or FlatBuffers(module, self.device)
 
         self.on_cuda = self.device.type == "cuda"
-        self.comm_stream = torch.cuda.Stream(self.device) if self.on_cuda else None
+        self.comm_stream = (new_stream(self.device, avoid=[getattr(module, "side_stream", None)])
+                            if self.on_cuda else None)
         self._done_events: List = []
         self._armed = True
         self._pending = [0] * len(self.arena.segments)

@@ -18,6 +18,7 @@ import torch
 import torch.distributed as dist
 
 from .. import comm, ops
+from ..utils.streams import new_stream
 
 Transfer = Tuple[torch.Tensor, int]          # (tensor, GLOBAL rank of the peer)
 
@@ -45,7 +46,7 @@ class P2PChannel:
         self._pending = {}
         if (self.device.type == "cuda" and comm.is_dist() and comm.backend_of(group) == "nccl" and ops.have_ext()
                 and os.environ.get("DDL_NATIVE_P2P", "1") == "1"):
-            self.stream = torch.cuda.Stream(self.device)
+            self.stream = new_stream(self.device)
             s = self.stream
             self.native = ops.require_ext().P2PEngine(
                 group if group is not None else dist.group.WORLD, s.stream_id, s.device_index, s.device_type,
