@@ -154,3 +154,15 @@ def test_copy_inputs_single_launch(dev):
     dxs = torch.zeros_like(xs)
     ops.copy_inputs(dxs, xs, dy, y)
     assert torch.equal(dxs, xs)
+
+
+def test_new_stream_never_returns_the_capture_stream_or_an_avoided_one():
+    """torch's stream pool is 32 streams handed out round-robin: 70 draws pass every pool entry at least twice."""
+    from ddl.utils.streams import capture_stream, new_stream
+    dev = torch.device("cuda", 0)
+    cap = capture_stream()
+    assert cap is not None and cap == torch.cuda.graph.default_capture_stream
+    other = new_stream(dev)
+    for _ in range(70):
+        s = new_stream(dev, avoid=[other, None])
+        assert s != cap and s != other
