@@ -134,3 +134,28 @@ def test_segments_split_evenly_for_every_world_size(world, bucket_mb):
         for s, e in ranges:
             seen[s:e] += 1
     assert bool((seen == 1).all())                             # shards tile the arena: no gap, no overlap
+
+
+def test_fused_zero_grad_leaves_a_clean_arena_and_the_same_losses():
+    """``GraphedTrainStep(fuse_zero_grad=True)``: the Adam pass clears the gradients it consumed, so no step starts
+    with a memset (reference order zero_grad -> forward -> backward -> step, single.py:137-154, same result);
+    ``--log-gradients`` keeps them readable after the step."""
+    import torch
+    from ddl import comm
+    from ddl.config import TrainConfig
+    from ddl.trainer import SingleStrategy
+    dev = torch.device("cpu")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(0, 256, (2, 3, 32, 32), dtype=torch.uint8, generator=g)
+    y = torch.randint(0, 5, (2,), generator=g)
+    runs = {}
+    for log in (False, True):
+        torch.manual_seed(0)
+        strat = SingleStrategy(TrainConfig(strategy="single", batch_size=2, log_gradients=log),
+                               comm.CommContext(0, 1, 0, dev, "none"))
+        assert strat._step.fuse_zero_grad == (not log)
+        losses = [float(strat.train_step(x, y, 2)[0]) for _ in range(3)]
+        gnorm = float(strat.optimizer.arena.flat_grad.abs().sum())
+        assert (gnorm == 0.0) == (not log)
+        runs[log] = losses
+    assert runs[False] == runs[True]
