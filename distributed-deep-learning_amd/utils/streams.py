@@ -4,8 +4,8 @@
 ``torch.cuda.graph`` captures on ONE class-level stream drawn from the same pool.  In a long-lived process (the test
 suite is one) every 32nd stream drawn is therefore the capture stream itself, and two engines can be handed the same
 stream.  Nothing breaks numerically when that happens - work just serialises - except a fork from a stream into
-itself during capture.  ``new_stream`` draws until the stream differs from the capture stream and from every stream
-the caller names."""
+itself during capture.  ``new_stream`` draws until the stream differs from the capture stream (when torch has
+drawn it already) and from every stream the caller names."""
 from __future__ import annotations
 
 from typing import Iterable, Optional
@@ -14,12 +14,11 @@ import torch
 
 
 def capture_stream() -> Optional["torch.cuda.Stream"]:
-    """The stream ``torch.cuda.graph`` captures on by default (created on first use, as torch itself does)."""
-    if not torch.cuda.is_available():
-        return None
-    if torch.cuda.graph.default_capture_stream is None:
-        torch.cuda.graph.default_capture_stream = torch.cuda.Stream()
-    return torch.cuda.graph.default_capture_stream
+    """The stream ``torch.cuda.graph`` captures on by default, if torch has drawn it already.  It is NOT created
+    here: torch draws it on the device that is current at the first capture, and drawing it earlier - before a rank
+    has selected its device - would pin every later capture to the wrong GPU.  A stage whose side stream turns out
+    to be the capture stream drawn later redraws at its first fork (``NativeDenseNetStage.fork``)."""
+    return getattr(torch.cuda.graph, "default_capture_stream", None)
 
 
 def new_stream(device, avoid: Iterable = (), priority: int = 0) -> "torch.cuda.Stream":

@@ -160,6 +160,8 @@ def test_new_stream_never_returns_the_capture_stream_or_an_avoided_one():
     """torch's stream pool is 32 streams handed out round-robin: 70 draws pass every pool entry at least twice."""
     from ddl.utils.streams import capture_stream, new_stream
     dev = torch.device("cuda", 0)
+    if torch.cuda.graph.default_capture_stream is None:        # what the first torch.cuda.graph() of a process does
+        torch.cuda.graph.default_capture_stream = torch.cuda.Stream()
     cap = capture_stream()
     assert cap is not None and cap == torch.cuda.graph.default_capture_stream
     other = new_stream(dev)
