@@ -11,11 +11,19 @@ fused softmax-CE, backward, bucketed RCCL reduce-scatter + all-gather (or all-re
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  Scaling is weak (per-GPU batch fixed).  ``--mode pp|ddpnpp``
-benchmarks the pipeline / hybrid strategies instead of DDP; ``--preset mi355x`` sizes them for the
-hardware (per-replica batch 240 = 8 micro-batches of 30, stages balanced on measured unit times)
-where the default ``--preset parity`` keeps the reference's sizes (30 = 5 micro-batches of 6, split at
-denseblock3).
+Prints ONE JSON line on rank 0.  Scaling is weak by default (per-GPU batch 30 fixed); ``--scaling strong`` keeps the
+reference's GLOBAL batch of 30 (ddp.py:335: 15 per rank at W=2).  ``--mode pp|ddpnpp`` benchmarks the pipeline /
+hybrid strategies instead of DDP; ``--preset parity`` (default) keeps the reference's own sizes - pp: 30 = 5
+micro-batches of 6 (pp.py:365,378), ddpnpp: 10 per replica = 5 micro-batches of 2 (ddp_n_pp.py:371,404), split at
+denseblock3 - and ``--preset mi355x`` sizes them for the hardware (per-replica batch 240 = 8 micro-batches of 30,
+stages balanced on measured unit times).
+
+First contact: with more than one rank (or ``DDL_FORCE_COLLECTIVES=1``) a staged ladder runs before anything is
+built - barrier, all-reduce, the native bucket reducer on a scratch arena (both collective forms, value-checked), a
+grouped send/recv ring through the native P2P engine (pipeline modes) - then strategy construction, each eager
+priming step and the hipGraph capture are stages too.  Every stage prints a progress line on stderr and has its own
+watchdog: a hang names its stage and exits non-zero (``ddl/diagnostics.py``).  The JSON says what actually ran:
+``backend``, ``world``, ``distinct_devices``, ``ranks_per_device``; ``n_gpus`` counts distinct physical GPUs.
 
 Failure policy: a step that cannot be captured / run is a FAILED benchmark - the error is printed and the
 process exits non-zero (no silent re-measurement on another path).  ``host_bound`` in the JSON (and a
@@ -48,6 +56,12 @@ PRESETS = {
     "mi355x": dict(batch=240, microbatches=8, split="auto"),         # 8 micro-batches of 30: the single-GPU kernel regime
     "mi355x-large": dict(batch=1024, microbatches=8, split="auto"),  # 8 micro-batches of 128: where the kernels run at
 }                                                                    #   ~4,700 samples/s; ~40 GB of the 288 GB per stage
+# the hybrid's own reference shape: 10 images per DP replica = 5 micro-batches of 2 (ddp_n_pp.py:371,404)
+PRESETS_BY_MODE = {("ddpnpp", "parity"): dict(batch=10, microbatches=5, split="reference")}
+
+
+def preset_for(mode: str, name: str) -> dict:
+    return PRESETS_BY_MODE.get((mode, name), PRESETS[name])
 
 
 def main() -> None:
@@ -65,8 +79,20 @@ def main() -> None:
     ap.add_argument("--split-points", nargs="+", default=None,
                     help="stage starts (reference module names) or 'auto' (balance on measured unit times)")
     ap.add_argument("--bucket-mb", type=float, default=8.0)
-    ap.add_argument("--grad-sync", choices=["rs_ag", "allreduce"], default=None,
-                    help="per-bucket collective (default: TrainConfig.grad_sync)")
+    ap.add_argument("--grad-sync", choices=["rs_ag", "allreduce", "auto"], default=None,
+                    help="per-bucket collective (default: TrainConfig.grad_sync; auto = time both on the captured step "
+                         "during priming and keep the faster one - all ranks agree through a max-reduce)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="ddp mode: weak = 30 images per GPU (default), strong = the reference's GLOBAL batch of 30 "
+                         "split over the ranks (ddp.py:335: 15 per rank at W=2)")
+    ap.add_argument("--image-size", type=int, default=224, help="input resolution (224 = the reference; anything else "
+                                                                "is a plumbing run and says so in the JSON)")
+    ap.add_argument("--ladder", default="auto", choices=["auto", "on", "off"],
+                    help="first-contact ladder before anything is built (auto: when W>1 or DDL_FORCE_COLLECTIVES=1)")
+    ap.add_argument("--stage-timeout", type=float, default=180.0,
+                    help="seconds one first-contact / priming stage may take before the run names it and exits 4")
+    ap.add_argument("--lanes", type=int, default=None, help="pipeline modes: concurrent micro-batch lanes per stage "
+                                                            "(default: TrainConfig.pp_lanes)")
     ap.add_argument("--zero1", action="store_true")
     ap.add_argument("--sync-buffers", default="forward", choices=["forward", "epoch", "off"],
                     help="BN buffer broadcast policy (forward = DDP parity, the default)")
@@ -91,21 +117,36 @@ def main() -> None:
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
-    from ddl import comm
+    from ddl import comm, diagnostics
     from ddl.config import TrainConfig
     from ddl.models.densenet import default_split_points
     from ddl.trainer import build_strategy
 
+    diagnostics.refuse_wrong_result_switches("bench.py")          # DDL_KNOCKOUT & co: exit 5
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus and world > 1:
         a.gpus = world
     if world > 1:
         a.profile = True      # event-based compute / RCCL / exposed-communication split (no host sync in the loop)
-    ctx = comm.init(a.backend, "auto", force=True)
+    rank_env = int(os.environ.get("RANK", "0"))
+    wd = diagnostics.StageWatchdog(rank_env, "bench.py", exit_code=4, quiet=(world == 1 and not comm.force_collectives()))
+    with wd.stage("process group init (rendezvous on MASTER_ADDR)", a.stage_timeout):
+        ctx = comm.init(a.backend, "auto", force=True)
     dev = ctx.device
-    preset = PRESETS[a.preset]
+    preset = preset_for(a.mode, a.preset)
     pipeline = a.mode != "ddp"
-    B = a.batch_per_gpu if a.batch_per_gpu is not None else (preset["batch"] if pipeline else 30)
+    if a.batch_per_gpu is not None:
+        B = a.batch_per_gpu
+    elif pipeline:
+        B = preset["batch"]
+    elif a.scaling == "strong":
+        if 30 % world:
+            print(f"bench.py: --scaling strong splits the reference's global batch of 30 over the ranks; "
+                  f"{world} does not divide 30", file=sys.stderr, flush=True)
+            os._exit(2)
+        B = 30 // world                                           # ddp.py:335 (15 at W=2)
+    else:
+        B = 30
     n_mb = a.microbatches if a.microbatches is not None else preset["microbatches"]
     strategy_name = a.mode
     pp_size = a.pp_size if a.mode != "ddp" else 1
@@ -118,15 +159,18 @@ def main() -> None:
     else:
         split = default_split_points(max(pp_size, 1))
 
+    tune_grad_sync = a.grad_sync == "auto"
+
     def make_strategy(bucket_mb: float, grad_phases=None):
         gp = a.grad_phases if grad_phases is None else grad_phases
-        cfg = TrainConfig(strategy=strategy_name, batch_size=B, dtype=a.dtype,
+        cfg = TrainConfig(strategy=strategy_name, batch_size=B, dtype=a.dtype, image_size=a.image_size,
                           bucket_mb=bucket_mb, zero1=a.zero1, hip_graph=not a.no_graph,
                           num_microbatches=n_mb, schedule=a.schedule, pp_size=pp_size,
                           split_points=split, profile=a.profile,
                           sync_buffers=a.sync_buffers, num_workers=0,
                           **({} if gp is None else {"grad_phases": gp}),
-                          **({} if a.grad_sync is None else {"grad_sync": a.grad_sync}))
+                          **({} if a.lanes is None else {"pp_lanes": a.lanes}),
+                          **({} if (a.grad_sync is None or tune_grad_sync) else {"grad_sync": a.grad_sync}))
         return build_strategy(cfg, ctx)
 
     def fail(stage: str, e: BaseException) -> None:
@@ -137,8 +181,21 @@ def main() -> None:
         sys.stdout.flush()
         os._exit(3)
 
+    # ---- first contact (ddl/diagnostics.py): who is here, then one rung at a time -------------------------------
     try:
-        strat = make_strategy(a.bucket_mb)
+        with wd.stage("topology all-gather", a.stage_timeout):
+            topo = diagnostics.topology(ctx)
+        if ctx.rank == 0 and not wd.quiet:
+            print(f"[rank 0] bench.py: world {topo['world']} over {topo['backend']}, {topo['distinct_devices']} distinct "
+                  f"device(s), {topo['ranks_per_device']} rank(s) per device: {topo['device_ids']}", file=sys.stderr, flush=True)
+        ladder_on = a.ladder == "on" or (a.ladder == "auto" and (world > 1 or comm.force_collectives()))
+        ladder = diagnostics.first_contact_ladder(ctx, pipeline, wd, a.stage_timeout) if ladder_on else []
+    except BaseException as e:      # noqa: BLE001
+        fail("the first-contact ladder", e)
+
+    try:
+        with wd.stage("strategy construction (parameter broadcast, sub-groups, auto split)", max(a.stage_timeout, 600.0)):
+            strat = make_strategy(a.bucket_mb)
     except BaseException as e:      # noqa: BLE001
         fail("strategy construction", e)
     dp = strat.dp_size
@@ -146,7 +203,7 @@ def main() -> None:
     g = torch.Generator().manual_seed(1234 + ctx.rank)
     pool = []
     for _ in range(4):
-        x = torch.randint(0, 256, (B, 3, 224, 224), dtype=torch.uint8, generator=g).to(dev)
+        x = torch.randint(0, 256, (B, 3, a.image_size, a.image_size), dtype=torch.uint8, generator=g).to(dev)
         y = torch.randint(0, 5, (B,), dtype=torch.int64, generator=g).to(dev)
         pool.append((x if strat.needs_input else None, y if strat.needs_target else None))
 
@@ -180,13 +237,39 @@ def main() -> None:
     # when the driver asks for fewer warm-up steps than that.
     PRIME = 3
     strat.model.train()
+    graph_mode = "off" if (a.no_graph or dev.type != "cuda") else "hipGraph"
+    engine = getattr(strat, "dp", None)
+    grad_sync_tuned = None
     try:
-        run_steps(strat, PRIME + a.warmup)
-        if dev.type == "cuda":
-            torch.cuda.synchronize(dev)
+        for i in range(PRIME):
+            # the graphed steps run 2 eager steps per new shape and capture on the third (utils/graph.py, pp._GraphSet)
+            what = ("eager" if (i < 2 or graph_mode == "off") else "hipGraph capture + first replay")
+            with wd.stage(f"priming step {i} ({what})", a.stage_timeout):
+                run_steps(strat, 1, first=i)
+                if dev.type == "cuda":
+                    torch.cuda.synchronize(dev)
+        if tune_grad_sync and engine is not None and not engine.single and not a.zero1:
+            # per-bucket collective form chosen by measurement on THIS machine and world size: the forms can be
+            # switched between two steps (collectives live outside the captured graphs)
+            with wd.stage("grad-sync tuning (rs_ag vs allreduce on the captured step)", a.stage_timeout):
+                grad_sync_tuned = {}
+                for mode in ("rs_ag", "allreduce"):
+                    engine.set_grad_sync(mode)
+                    run_steps(strat, 2)
+                    sync()
+                    t0 = time.perf_counter()
+                    run_steps(strat, 8)
+                    sync()
+                    grad_sync_tuned[mode] = round(max_over_ranks(time.perf_counter() - t0) / 8 * 1e3, 3)
+                best = min(grad_sync_tuned, key=grad_sync_tuned.get)       # identical on every rank (max-reduced times)
+                engine.set_grad_sync(best)
+                grad_sync_tuned["chosen"] = best
+        with wd.stage(f"{a.warmup} warm-up steps", max(a.stage_timeout, 2.0 * a.warmup)):
+            run_steps(strat, a.warmup)
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
     except BaseException as e:      # noqa: BLE001
         fail("warm-up / hipGraph capture", e)
-    graph_mode = "off" if (a.no_graph or dev.type != "cuda") else "hipGraph"
 
     # The per-step compute / RCCL split costs ~1 % (timing events on every stream), so the profiler is paused for
     # the timed steps and the split is measured on extra steps behind them ("profile_steps" in the JSON).
@@ -194,7 +277,8 @@ def main() -> None:
     if a.profile:
         strat.profiler.set_enabled(False)
     try:
-        dt, host_dt = timed(strat, a.steps)
+        with wd.stage(f"the {a.steps} timed steps", max(a.stage_timeout, 2.0 * a.steps)):
+            dt, host_dt = timed(strat, a.steps)
     except BaseException as e:      # noqa: BLE001
         fail("the timed steps", e)
     dt = max_over_ranks(dt)
@@ -248,7 +332,6 @@ def main() -> None:
         st.tick()
         sync()
 
-    engine = getattr(strat, "dp", None)
     global_batch = B * dp
     value = global_batch * a.steps / dt
     base_key = "single" if (a.mode == "ddp" and world == 1) else a.mode
@@ -256,15 +339,19 @@ def main() -> None:
         "metric": "samples/sec (whole job), DenseNet-121 training",
         "value": round(value, 2),
         "unit": "samples/s",
-        "n_gpus": world,
+        "n_gpus": topo["n_gpus"],
+        "world": topo["world"],
+        "backend": topo["backend"],
+        "distinct_devices": topo["distinct_devices"],
+        "ranks_per_device": topo["ranks_per_device"],
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": round(step_ms, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": a.scaling if a.mode == "ddp" else "weak",
         "vs_baseline": round(value / BASELINE[base_key], 2),
         "dtype": a.dtype,
-        "data": "synthetic uint8 3x224x224 images generated on device, random-init weights",
+        "data": f"synthetic uint8 3x{a.image_size}x{a.image_size} images generated on device, random-init weights",
         "host_issue_ms_per_step": round(host_ms, 3),
         "host_issue_queued_ms_per_step": round(queued_ms, 3),
         "host_bound": bool(host_bound),
@@ -273,7 +360,7 @@ def main() -> None:
             "global_batch": global_batch,
             "batch_per_gpu": B,
             "seq_len": None,
-            "image": "3x224x224",
+            "image": f"3x{a.image_size}x{a.image_size}",
             "optimizer": "Adam(lr=1e-3) fused flat",
             "parallelism": (f"dp{dp}" if a.mode == "ddp" else
                             f"pp{pp_size}" if a.mode == "pp" else f"dp{dp}xpp{pp_size}"),
@@ -291,7 +378,17 @@ def main() -> None:
     }
     if pipeline:
         out["config"].update(preset=a.preset, microbatches=n_mb, schedule=a.schedule,
-                             split_points=list(getattr(strat, "split_points", split)))
+                             split_points=list(getattr(strat, "split_points", split)),
+                             lanes=getattr(getattr(strat, "stage", None), "n_lanes", 1))
+    if ladder:
+        out["first_contact_ladder"] = ladder          # rungs that completed (value-checked) before anything was built
+    if grad_sync_tuned is not None:
+        out["grad_sync_tuned"] = grad_sync_tuned
+    exp_env = diagnostics.experimental_env()
+    if exp_env:
+        out["experimental_env"] = exp_env             # every DDL_* switch that was set: nothing changes the path silently
+    if a.image_size != 224 or topo["n_gpus"] == 0 or topo["ranks_per_device"] > 1:
+        out["plumbing_run"] = True                    # not a headline configuration (shared device / CPU / small images)
     if profile is not None:
         out["profile"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in profile.items()}
 

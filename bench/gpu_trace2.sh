@@ -1,5 +1,6 @@
 #!/bin/bash
 # kernel traces of the default step with fused statistics on / off (eager launches, last step)
+export DDL_EXPERIMENTAL=1   # experiment switches are ignored without it (ddl/utils/knobs.py)
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/prof

@@ -1,6 +1,7 @@
 #!/bin/bash
 # in-step A/B of tile configurations: one DDL_CFG_RULES override per run, same box, batch 30
 # rule = kind:taps:minM:maxM:cfg   (M at batch 30: block 1 94080, block 2 23520, block 3 5880, block 4 1470)
+export DDL_EXPERIMENTAL=1   # experiment switches are ignored without it (ddl/utils/knobs.py)
 set -o pipefail
 O=$GRAFT_REPO_ROOT/gpurun_out/cfgab
 mkdir -p $O

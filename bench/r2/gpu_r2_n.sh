@@ -1,4 +1,5 @@
 #!/bin/bash
+export DDL_EXPERIMENTAL=1   # experiment switches are ignored without it (ddl/utils/knobs.py)
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r2n

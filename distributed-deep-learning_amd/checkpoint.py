@@ -26,8 +26,9 @@ stale ``epochs_run``; the checkpoint directory itself is created.
 """
 from __future__ import annotations
 
+import json
 import os
-from typing import Any, Dict, Optional
+from typing import Any, Dict, List, Optional, Sequence
 
 import torch
 import torch.distributed.checkpoint as dcp
@@ -154,6 +155,44 @@ def load_snapshot(path: str, model, optimizer, suffix: str = "", process_group=N
     app = AppState(0, model, optimizer, suffix)
     dcp.load({"app": app}, checkpoint_id=path, process_group=process_group)
     return app.epoch
+
+
+PARTITION_FILE = "partition.json"
+
+
+def save_partition(path: str, split_points: Sequence[str]) -> None:
+    """Sidecar of a pipeline snapshot: the RESOLVED stage boundaries.  Snapshots are keyed ``model{stage}`` /
+    ``optim{stage}`` like the reference's (pp.py:87-88), so a resumed run must rebuild exactly the stages that were
+    saved - ``--split-points auto`` re-measures unit times and may move a cut by one dense layer otherwise."""
+    tmp = os.path.join(path, PARTITION_FILE + ".tmp")
+    with open(tmp, "w") as f:
+        json.dump({"split_points": list(split_points), "num_stages": len(split_points) + 1}, f)
+    os.replace(tmp, os.path.join(path, PARTITION_FILE))
+
+
+def load_partition(path: Optional[str]) -> Optional[List[str]]:
+    if not path:
+        return None
+    f = os.path.join(path, PARTITION_FILE)
+    if not os.path.exists(f):
+        return None
+    with open(f) as fh:
+        return list(json.load(fh)["split_points"])
+
+
+def resume_path(ckpt_subdir: str, job_id: str, snapshot_job_id: Optional[str], snapshot_epoch: Optional[int],
+                resume_latest: bool) -> Optional[str]:
+    """The snapshot directory a run with these flags resumes from (None: fresh start).  One rule for the trainer
+    (which loads it) and the pipeline strategy (which must know the saved partition BEFORE it builds its stage)."""
+    job, epoch = snapshot_job_id, snapshot_epoch
+    if resume_latest and job is None:
+        latest = latest_snapshot(ckpt_subdir, job_id)
+        if latest is not None:
+            job, epoch = job_id, latest
+    if job is None or epoch is None:
+        return None
+    path = snapshot_path(ckpt_subdir, job, epoch)
+    return path if os.path.exists(path) else None                 # single.py:115-119
 
 
 def latest_snapshot(ckpt_dir: str, job_id: str) -> Optional[int]:

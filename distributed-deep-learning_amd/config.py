@@ -67,6 +67,8 @@ class TrainConfig:
     # ---- pipeline parallel (reference: pp.py:378-386) ------------------------
     num_microbatches: int = 5
     schedule: str = "1f1b"              # 1f1b | gpipe
+    pp_lanes: int = 1                   # concurrent micro-batch lanes per stage (parallel/pp.py "lanes"): backward of
+    #                                     micro-batch i next to the forward of i+k on separate streams / graph pools
     split_points: List[str] = field(default_factory=lambda: ["features.denseblock3.denselayer1"])
     # ---- 2-D mesh (reference: ddp_n_pp.py:32-33) -----------------------------
     dp_size: int = 0                    # 0: world_size // pp_size

@@ -47,6 +47,8 @@ void copy_pair(at::Tensor dst_a, const at::Tensor& src_a, at::Tensor dst_b, cons
   }
   TORCH_CHECK(dst_a.scalar_type() == src_a.scalar_type() && dst_a.sizes() == src_a.sizes() &&
                   dst_b.scalar_type() == src_b.scalar_type() && dst_b.sizes() == src_b.sizes(), "copy_pair: shape / dtype");
+  TORCH_CHECK(src_a.device() == dst_a.device() && src_b.device() == dst_a.device() && dst_b.device() == dst_a.device(),
+              "copy_pair: all four tensors must live on one device (the launch runs under dst_a's device guard)");
   const int64_t na = dst_a.numel() * dst_a.element_size(), nb = dst_b.numel() * dst_b.element_size();
   TORCH_CHECK(na % 16 == 0 && reinterpret_cast<uintptr_t>(dst_a.data_ptr()) % 16 == 0 &&
                   reinterpret_cast<uintptr_t>(src_a.data_ptr()) % 16 == 0, "copy_pair: 16-byte granularity for the first pair");

@@ -182,7 +182,7 @@ at::Tensor conv_gemm(const at::Tensor& x0, const OptT& x1, const OptT& s0, const
                 "tail prep: count, mean, rstd, scale, dgamma, dbeta, k1, k2");
     p.tail.counters = reinterpret_cast<unsigned*>(ct.data_ptr<int>());
     p.tail.mode = (int)tail_mode;
-    static const int tail_fence = [] { const char* e = getenv("DDL_TAIL_FENCE"); return (e && e[0] == '1') ? 1 : 0; }();
+    static const int tail_fence = [] { const char* e = ddl_knob("DDL_TAIL_FENCE"); return (e && e[0] == '1') ? 1 : 0; }();
     p.tail.fence = tail_fence;
     p.tail.inv_count = 1.0 / tail_count;
     p.tail.mean = fvec(*tail_mean, N, "tail_mean"); p.tail.rstd = fvec(*tail_rstd, N, "tail_rstd");
@@ -338,7 +338,7 @@ void conv_wgrad(const at::Tensor& d0, const OptT& d1, const OptT& ds0, const Opt
     other = (int)(3 * ((C + 127) / 128));
   }
   // resident workgroup slots: 1x1 with 128-column tiles 2 per CU (64 KB LDS), 32-column tiles 3-4 per CU (40 KB, registers)
-  static const int target1 = [] { const char* e = getenv("DDL_WGRAD_TARGET1"); return e ? atoi(e) : 512; }();
+  static const int target1 = [] { const char* e = ddl_knob("DDL_WGRAD_TARGET1"); return e ? atoi(e) : 512; }();
   p.rows_per_wg = ddl::wgrad_rows_per_wg((int)M, other, (int)min_rows, taps == 1 ? (p.sub == 1 ? target1 : 512) : 768);
   p.S = (int)((M + p.rows_per_wg - 1) / p.rows_per_wg);
   auto slabs = at::empty({p.S, N, taps * C}, d0.options());
@@ -398,7 +398,7 @@ void conv_wgrad_group(int64_t taps, std::vector<at::Tensor> d0, std::vector<at::
     slab_elems += N * taps * C;
   }
   // pixel chunking: about `target` workgroups in all (two rounds of the resident slots), every chunk >= 4 steps
-  static const int target = [] { const char* e = getenv("DDL_WGRAD_GROUP_WGS"); return e ? atoi(e) : 768; }();
+  static const int target = [] { const char* e = ddl_knob("DDL_WGRAD_GROUP_WGS"); return e ? atoi(e) : 768; }();
   int64_t chunks = (target + tiles - 1) / tiles;
   int64_t rows = (M + chunks - 1) / chunks;
   if (rows < 128) rows = 128;

@@ -509,7 +509,7 @@ struct CfgRule { int kind, taps; long lo, hi; int cfg; };
 static const std::vector<CfgRule>& cfg_rules() {
   static const std::vector<CfgRule> rules = [] {
     std::vector<CfgRule> r;
-    const char* e = getenv("DDL_CFG_RULES");
+    const char* e = ddl_knob("DDL_CFG_RULES");
     if (e == nullptr) return r;
     std::string s(e);
     size_t pos = 0;
@@ -566,7 +566,7 @@ int pick_cfg(const ConvGemmParams& p, int force) {
 // `force` == 2000 / 2001 sends an eligible 3x3 problem to the big / small halo kernel whatever its size, any other
 // non-zero value keeps it on the conv_gemm tiles (tests / bench/kernel_bench.py); DDL_HALO=0 disables both.
 static int halo_bm(const ConvGemmParams& p, int force) {
-  static const bool enabled = [] { const char* e = getenv("DDL_HALO"); return !(e && e[0] == '0'); }();
+  static const bool enabled = [] { const char* e = ddl_knob("DDL_HALO"); return !(e && e[0] == '0'); }();
   if (!enabled) return 0;
   return conv3x3_halo_bm(p, force);
 }

@@ -475,7 +475,7 @@ int wgrad_rows_per_wg(int M, int other_grid, int min_rows, int target_wgs) {
 //    where the channel axis supplies the workgroups and the slab volume S x N x C x 4 B shrinks with S;
 //  * tiles are balanced: ctiles = ceil(nsub / SUB), then SUB = ceil(nsub / ctiles).
 void wgrad1x1_tiling(int M, int C, int N, int force_sub, int& sub, int& ctiles) {
-  static const int min_steps = [] { const char* e = getenv("DDL_WGRAD_MIN_STEPS"); return e ? atoi(e) : 2; }();
+  static const int min_steps = [] { const char* e = ddl_knob("DDL_WGRAD_MIN_STEPS"); return e ? atoi(e) : 2; }();
   const int nsub = (C + 31) / 32, ntiles = (N + 127) / 128;
   auto balanced = [&](int want, int& sb, int& ct) {
     ct = (nsub + want - 1) / want;
@@ -514,7 +514,7 @@ void launch_wgrad(const WgradParams& p, hipStream_t s) {
 #define DDL_W1(SUBV, PFV)                                                                                    \
     if (two) hipLaunchKernelGGL((wgrad1x1_kernel<SUBV, true, PFV>), grid, dim3(256), lds1(SUBV), s, p);        \
     else hipLaunchKernelGGL((wgrad1x1_kernel<SUBV, false, PFV>), grid, dim3(256), lds1(SUBV), s, p)
-    static const bool pf2 = [] { const char* e = getenv("DDL_WGRAD_PF2"); return !(e && e[0] == '0'); }();
+    static const bool pf2 = [] { const char* e = ddl_knob("DDL_WGRAD_PF2"); return !(e && e[0] == '0'); }();
     switch (p.sub) {
       case 1: if (pf2) { DDL_W1(1, 2); } else { DDL_W1(1, 1); } break;
       case 3: DDL_W1(3, 1); break;
@@ -534,8 +534,8 @@ void launch_wgrad_group(WgradGroupParams& g, hipStream_t s) {
   // DDL_WGRAD_GROUP_LDS1 / _LDS9: LDS bytes REQUESTED per workgroup (>= what the kernel uses).  Asking for more
   // lowers the number of co-resident weight-gradient workgroups per CU, which leaves LDS / registers for the
   // (latency-critical) data-gradient chain that runs beside them.
-  static const size_t want1 = [] { const char* e = getenv("DDL_WGRAD_GROUP_LDS1"); return e ? (size_t)atol(e) : 0; }();
-  static const size_t want9 = [] { const char* e = getenv("DDL_WGRAD_GROUP_LDS9"); return e ? (size_t)atol(e) : 0; }();
+  static const size_t want1 = [] { const char* e = ddl_knob("DDL_WGRAD_GROUP_LDS1"); return e ? (size_t)atol(e) : 0; }();
+  static const size_t want9 = [] { const char* e = ddl_knob("DDL_WGRAD_GROUP_LDS9"); return e ? (size_t)atol(e) : 0; }();
   size_t lds1 = (size_t)2 * RK * (128 + 128) * sizeof(float);
   size_t lds3 = (size_t)(2 * RK * 32 + 2 * (RK + 2) * 128 + 2 * RK) * sizeof(float);
   if (want1 > lds1) lds1 = want1;

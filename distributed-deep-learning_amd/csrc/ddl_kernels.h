@@ -4,8 +4,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
+
+// Experiment switches of the kernels' host side (tile overrides, chunking targets, ...): the defaults are the measured
+// optimum, so a variable is honoured only under DDL_EXPERIMENTAL=1 - a stray DDL_* variable in somebody's shell never
+// changes the code path of a production run (bench.py lists every DDL_* variable it saw: "experimental_env").
+inline const char* ddl_knob(const char* name) {
+  static const bool on = [] { const char* e = std::getenv("DDL_EXPERIMENTAL"); return e && e[0] == '1'; }();
+  return on ? std::getenv(name) : nullptr;
+}
 
 // host-side HIP calls of the launchers (attribute set-up): fail loudly, pybind turns it into a RuntimeError
 #define DDL_HIP_CHECK(expr)                                                                              \

@@ -122,6 +122,19 @@ class P2PEngine {
     done_.clear();
   }
 
+  // Order everything posted from now on behind what the compute stream has enqueued so far.  The schedules call it
+  // at the end of every step: the next step pre-posts receives into the SAME per-micro-batch slots, and nothing
+  // else keeps such a receive from landing before the forward that still reads the slot has run (an evaluation
+  // loop has no backward chain and no host sync; under hipGraph replay the host runs far ahead).
+  void fence() {
+    if (serialize_) return;
+    const Stream main = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(p2p_.device_index());
+    Event consumed;
+    consumed.record(main);
+    consumed.block(p2p_);
+    ++fences_;
+  }
+
   double drain_ms() {
     double ms = 0.0;
     for (auto& s : spans_) {
@@ -140,7 +153,7 @@ class P2PEngine {
   c10::intrusive_ptr<c10d::ProcessGroup> pg_;
   Stream p2p_;
   bool serialize_, timing_;
-  int64_t next_ = 0, groups_ = 0;
+  int64_t next_ = 0, groups_ = 0, fences_ = 0;
   std::map<int64_t, std::unique_ptr<Event>> done_;
   std::vector<std::pair<std::unique_ptr<Event>, std::unique_ptr<Event>>> spans_;
 };
@@ -156,6 +169,7 @@ void register_p2p(pybind11::module_& m) {
            pybind11::arg("recv_peers"), pybind11::arg("after_compute"))
       .def("wait", &P2PEngine::wait)
       .def("drain", &P2PEngine::drain)
+      .def("fence", &P2PEngine::fence)
       .def("drain_ms", &P2PEngine::drain_ms)
       .def("set_timing", &P2PEngine::set_timing)
       .def_property_readonly("groups", &P2PEngine::groups)

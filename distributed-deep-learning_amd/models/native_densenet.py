@@ -35,8 +35,6 @@ Weight layouts (converted at the checkpoint boundary by ``ddl_export_tensor`` /
 """
 from __future__ import annotations
 
-import os
-
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -44,6 +42,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..utils.arena import FlatArena, FlatBuffers, reverse_named_parameters
+from ..utils.knobs import knob
 from ..utils.streams import new_stream
 from .densenet import (BLOCK_CONFIG, BN_SIZE, GROWTH, UNIT_NAMES, DenseNetStage, block_channels, parse_unit)
 
@@ -265,11 +264,6 @@ class _BlockFn(torch.autograd.Function):
         return dx, None, None
 
 
-# DDL_KNOCKOUT=wgrad|bnprep: leave a kernel class OUT of the grouped dense-block backward (results are wrong - this is
-# the timing experiment that shows what the step's wall clock depends on; README "What the step is made of")
-_KNOCK = os.environ.get("DDL_KNOCKOUT", "")
-
-
 def _backward_grouped(ext, unit, G, main, side, d2d, buf2d, nq, np_, stats, sc1, sh1, bn2, h, M, H, W, C0, L, bf,
                       acc, tickets):
     """Dense-block backward with LAYER-GROUPED weight gradients (csrc/conv_wgrad.hip: wgrad_group_kernel).
@@ -292,8 +286,6 @@ def _backward_grouped(ext, unit, G, main, side, d2d, buf2d, nq, np_, stats, sc1,
     tail = acc is not None
 
     def launch(group, set_):
-        if _KNOCK == "wgrad":
-            return
         q = ext.SlabQueue()
         sls = [slice(C0 + GROWTH * l, C0 + GROWTH * (l + 1)) for l in group]
         lays = [unit.layers[l] for l in group]
@@ -325,12 +317,12 @@ def _backward_grouped(ext, unit, G, main, side, d2d, buf2d, nq, np_, stats, sc1,
                       tail_k1=nq, tail_k2=np_)
         st = ext.conv_gemm(d2d[:, sl], buf2d[:, sl], ones[:GROWTH], nq[sl], np_[sl], False, M, H, W, 9, True,
                            lay.w2, True, g2[set_, slot], True, False, h[l], sc2, sh2, 2, 0, bf, **t3)
-        if not tail and _KNOCK != "bnprep":
+        if not tail:
             ext.bn_bwd_prep(st, float(M), bn2[l, 0], bn2[l, 2], sc2, lay.gg2, lay.gb2,
                             k[set_, slot, 0], k[set_, slot, 1], k[set_, slot, 2], MID, 0)
         st1 = ext.conv_gemm(g2[set_, slot], h[l], k[set_, slot, 0], k[set_, slot, 1], k[set_, slot, 2], False, M, H, W, 1,
                             False, lay.w1, True, d2d[:, :C], True, True, buf2d[:, :C], sc1[l], sh1[l], 2, 0, bf, **t1)
-        if not tail and _KNOCK != "bnprep":
+        if not tail:
             ext.bn_bwd_prep(st1, float(M), stats[0], stats[2], sc1[l], lay.gg1, lay.gb1, None, nq, np_, C, 1)
         grp.append(l)
         if len(grp) == G or l == 0:
@@ -626,15 +618,15 @@ class NativeDenseNetStage(nn.Module):
         # backward variant (BN2 coefficients derived inside the 1x1 dgrad / wgrad) removes 58 more launches
         # but its prologue work outweighs them once the two backward streams overlap inside a hipGraph
         # (10.23 ms), so it is opt-in: DDL_FUSED_BWD=1 (it does win with eager launches).
-        self.fused_stats = os.environ.get("DDL_FUSED_STATS", "1") == "1"
-        self.fused_bwd = os.environ.get("DDL_FUSED_BWD", "0") == "1"
+        self.fused_stats = knob("DDL_FUSED_STATS", "1") == "1"
+        self.fused_bwd = knob("DDL_FUSED_BWD", "0") == "1"
         # g2 / k buffers of the dense-block backward: how many layers the weight-gradient stream may lag
-        self.g2_bufs = max(1, int(os.environ.get("DDL_G2_BUFS", "2")))
+        self.g2_bufs = max(1, int(knob("DDL_G2_BUFS", "2")))
         # slab reductions of the weight gradients (csrc/conv_bindings.cpp SlabQueue): "layer" = one launch per dense
         # layer for its 3x3 + 1x1 slabs (58 fewer graph nodes than one per kernel); "block" = one per dense block
         # (116 fewer nodes, but measured 0.4 ms/step SLOWER at batch 30: the slabs of 24 layers no longer fit the
         # 256 MB Infinity Cache and come back from HBM); "0" = behind every kernel
-        d = os.environ.get("DDL_DEFER_SLABS", "layer")
+        d = knob("DDL_DEFER_SLABS", "layer")
         self.defer_slab_reduce = d if d in ("layer", "block") else ""
         ops.require_ext()
         device = torch.device(device)
@@ -672,8 +664,8 @@ class NativeDenseNetStage(nn.Module):
         self.anchor = torch.zeros(1, device=device, requires_grad=True)   # keeps every unit in the graph
         self.side_stream = new_stream(device)
         self.overlap_wgrad = True
-        self._wgrad_group = os.environ.get("DDL_WGRAD_GROUP", "auto")
-        self.tail_prep = os.environ.get("DDL_TAIL_PREP", "1") == "1"      # csrc/conv_params.h TailPrep (grouped backward)
+        self._wgrad_group = knob("DDL_WGRAD_GROUP", "auto")
+        self.tail_prep = knob("DDL_TAIL_PREP", "1") == "1"      # csrc/conv_params.h TailPrep (grouped backward)
         self._fork_origin = None          # origin stream of the open side-stream fork (see ``fork``)
         self._owned_grad_ptr = 0          # data_ptr of the gradient a transition / head backward just produced
         self.ones = torch.ones(1024, device=device)
@@ -691,11 +683,20 @@ class NativeDenseNetStage(nn.Module):
         for a, b in zip(self.unit_objs[:-1], self.unit_objs[1:]):
             if isinstance(a, BlockUnit) and isinstance(b, (TransitionUnit, HeadUnit)):
                 a.defer_finalize = True         # b's bn_prep finalises a's last channel slice (one launch fewer)
-                b.defer_affine = os.environ.get("DDL_DEFER_AFFINE", "1") == "1"   # a adopts b's BN-backward k1 / k2
+                b.defer_affine = knob("DDL_DEFER_AFFINE", "1") == "1"   # a adopts b's BN-backward k1 / k2
                 a.next_unit = b
         self._pending_affine = None
+        # gradient lanes (parallel/pp.py "lanes"): lane 0 is the arena's own gradient buffer; further lanes are
+        # buffers of the same layout that concurrently running micro-batch backwards accumulate into.  A unit's
+        # views are rebound per lane (cached: rebinding happens at graph-capture time and in eager / --debug-sync
+        # steps only, never on the replay path).
+        self._grad_lanes: List[torch.Tensor] = [self.arena.flat_grad]
+        self._grad_lane = 0
         for u in self.unit_objs:
+            before = dict(vars(u))
             u.bind()
+            u._bind_keys = [k for k, v in vars(u).items() if k not in before or before[k] is not v]
+            u._lane_cache = {0: {k: getattr(u, k) for k in u._bind_keys}}
 
     def unit_of_param(self, fqn: str) -> str:
         """Unit of this stage that owns a parameter (torchvision FQN)."""
@@ -751,7 +752,37 @@ class NativeDenseNetStage(nn.Module):
     # ---- views ---------------------------------------------------------------------------
     def pv(self, fqn: str) -> Tuple[torch.Tensor, torch.Tensor]:
         i = self.param_index[fqn]
-        return self.arena.param_view(i), self.arena.grad_view(i)
+        return self.arena.param_view(i), self.arena.view_in(self._grad_lanes[self._grad_lane], i)
+
+    # ---- gradient lanes ------------------------------------------------------------------
+    def ensure_grad_lanes(self, n: int) -> None:
+        if self._grad_lanes[0] is not self.arena.flat_grad:
+            raise RuntimeError("the arena's gradient buffer was replaced after the stage was built")
+        while len(self._grad_lanes) < n:
+            self._grad_lanes.append(torch.zeros_like(self.arena.flat_grad))
+
+    def set_grad_lane(self, k: int) -> None:
+        """Kernels launched (or captured) from now on accumulate parameter gradients into gradient lane ``k``."""
+        if k == self._grad_lane:
+            return
+        if not 0 <= k < len(self._grad_lanes):
+            raise ValueError(f"gradient lane {k} of {len(self._grad_lanes)}")
+        self._grad_lane = k
+        for u in self.unit_objs:
+            cached = u._lane_cache.get(k)
+            if cached is None:
+                u.bind()
+                cached = u._lane_cache[k] = {key: getattr(u, key) for key in u._bind_keys}
+            else:
+                for key, val in cached.items():
+                    setattr(u, key, val)
+
+    def sum_grad_lanes(self) -> None:
+        """arena gradient += lane 1 + lane 2 + ... (fixed order), lanes cleared for the next step; back on lane 0."""
+        for lane in self._grad_lanes[1:]:
+            self.arena.flat_grad.add_(lane)
+            lane.zero_()
+        self.set_grad_lane(0)
 
     def bv(self, fqn: str) -> torch.Tensor:
         return self._buffers_by_name[fqn]
@@ -779,7 +810,7 @@ class NativeDenseNetStage(nn.Module):
         latency-bound 10-25 us kernel; keep the per-layer kernels where one layer already fills the chip."""
         g = self._wgrad_group
         if g == "auto":
-            for rule in os.environ.get("DDL_WGRAD_GROUPS", "").split(","):     # "minM:G,..." first match wins (experiments)
+            for rule in knob("DDL_WGRAD_GROUPS", "").split(","):     # "minM:G,..." first match wins (experiments)
                 if rule:
                     m, gg = rule.split(":")
                     if M >= int(m):

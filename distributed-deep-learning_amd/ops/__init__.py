@@ -17,6 +17,8 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 import torch.nn.functional as F
 
+from ..utils.knobs import knob
+
 _EXT = None
 _EXT_ERR: Optional[BaseException] = None
 
@@ -95,7 +97,8 @@ def cross_entropy_with_preds(logits: torch.Tensor, targets: torch.Tensor) -> Tup
 def copy_inputs(dst_x: torch.Tensor, x: torch.Tensor, dst_y: torch.Tensor, y: torch.Tensor) -> None:
     """``dst_x.copy_(x); dst_y.copy_(y)`` - on the GPU as ONE launch when the layout allows it (the two input copies
     in front of a graph replay; each eager operation between two graph launches is a queue round trip)."""
-    if (os.environ.get("DDL_COPY_PAIR", "1") == "1" and x.is_cuda and y.is_cuda and dst_x.is_cuda and have_ext()
+    if (knob("DDL_COPY_PAIR", "1") == "1" and x.is_cuda and y.is_cuda and dst_x.is_cuda and dst_y.is_cuda and have_ext()
+            and x.device == dst_x.device == y.device == dst_y.device
             and x.dtype == dst_x.dtype and y.dtype == dst_y.dtype and x.shape == dst_x.shape and y.shape == dst_y.shape
             and x.is_contiguous() and y.is_contiguous() and dst_x.is_contiguous() and dst_y.is_contiguous()
             and (x.numel() * x.element_size()) % 16 == 0 and x.data_ptr() % 16 == 0 and dst_x.data_ptr() % 16 == 0):

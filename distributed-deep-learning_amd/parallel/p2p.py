@@ -97,6 +97,13 @@ class P2PChannel:
         for w in self._pending.pop(ticket, ()):
             w.wait()
 
+    def fence(self) -> None:
+        """Transfers posted from now on start after everything the compute stream has enqueued so far (slot reuse
+        across steps: a pre-posted receive must not land before the previous step's consumer has read the slot).
+        The gloo twin is host-synchronous and needs nothing."""
+        if self.native is not None:
+            self.native.fence()
+
     def drain(self) -> None:
         if self.native is not None:
             self.native.drain()

@@ -32,15 +32,33 @@ What is different, MI355X-first:
     captured as a CHAIN of graphs cut at the stage's backward phases (``forward_phased``), and the
     gradient buckets a phase completed go to the comm stream before the next graph is enqueued.
 
+  * **lanes** (``n_lanes > 1``): the reference's shapes run micro-batches of 6 (pp.py) and 2 (ddp_n_pp.py), where
+    every kernel of the late dense blocks is a ~10 us latency-bound launch that leaves most of the 256 CUs idle -
+    one micro-batch after the other costs 23 ms per 30 images on one stage against 8.6 ms for one batch of 30.
+    Micro-batches are independent except for three shared objects, and each gets an ordered hand-off instead of a
+    serialised stage: BN running statistics change only in forwards -> ALL forwards replay in order on ONE forward
+    stream; gradients accumulate -> backward ``i`` replays on backward stream ``i % n_lanes`` and accumulates into
+    gradient arena ``i % n_lanes`` (lane 0 = the arena Adam / the reducer read; the others are added into it once
+    per step, in lane order - fixed arithmetic, so the run stays bit-deterministic); saved activations -> every
+    micro-batch graph keeps its own (separate graph pools per stream, autograd graphs retained: nothing two
+    concurrently replaying graphs touch is ever aliased).  So in 1F1B steady state ``B_i`` runs next to
+    ``F_{i+1}`` and ``B_{i+1}``; P2P groups are fenced against the stream that produced / consumes their
+    payload.  With a data-parallel reducer the LAST micro-batch's backward runs after the lanes have been joined
+    and summed, on the compute stream, so the reducer still overlaps exactly that backward (reference semantic).
+    ``--debug-sync`` / eager steps use the same lane arithmetic on one stream: the serial oracle of the overlapped
+    run (bit-identical parameters, ``tests/test_gpu_dist.py``).
+
 BatchNorm statistics are per micro-batch, exactly as in the reference.
 """
 from __future__ import annotations
 
+from contextlib import nullcontext
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 
 from .p2p import P2PChannel, Transfer
+from ..utils.streams import new_stream
 from ..utils.trace import trace_range
 
 
@@ -89,16 +107,18 @@ class _GraphSet:
         self.steps = 0
         self.active = False
         self.fwd, self.bwd = {}, {}
-        self._pool = None
+        self._pools = {}
 
     def begin_step(self) -> None:
         self.active = self.steps >= self.warmup
         self.steps += 1
 
-    def pool(self):
-        if self._pool is None:
-            self._pool = torch.cuda.graph_pool_handle()
-        return self._pool
+    def pool(self, key=None):
+        """One pool for a serial stage; with lanes one per stream (graphs of one pool replay in capture order on
+        one stream - graphs that replay concurrently must never share transient memory)."""
+        if key not in self._pools:
+            self._pools[key] = torch.cuda.graph_pool_handle()
+        return self._pools[key]
 
 
 class PipelineStage:
@@ -112,7 +132,7 @@ class PipelineStage:
                  group=None, ranks: Optional[Sequence[int]] = None,
                  recv_shape_fn: Optional[Callable[[int], Tuple[int, ...]]] = None,
                  dtype: torch.dtype = torch.float32, dp_engine=None, hip_graph: bool = False,
-                 graph_warmup: int = 2, debug_sync: bool = False, profiler=None) -> None:
+                 graph_warmup: int = 2, debug_sync: bool = False, profiler=None, n_lanes: int = 1) -> None:
         self.module = module
         self.stage_index = stage_index
         self.num_stages = num_stages
@@ -140,6 +160,17 @@ class PipelineStage:
                        and bool(getattr(module, "phase_starts", None)))
         self.launch_trace: List[Tuple[str, int]] = []     # ("graph" | "bucket", index) of the last phased backward
         self._cuts = {}
+        # lanes (module docstring): gradient-lane ARITHMETIC whenever the module can do it (eager, --debug-sync and
+        # graphed steps then compute the same bits), lane CONCURRENCY only when graphs replay on their own streams
+        self.n_lanes = max(1, int(n_lanes)) if hasattr(module, "set_grad_lane") else 1
+        if self.n_lanes > 1:
+            module.ensure_grad_lanes(self.n_lanes)
+        self.lanes_concurrent = self.hip_graph and self.n_lanes > 1 and not debug_sync
+        self.join_before_last = dp_engine is not None and not dp_engine.single
+        self.fwd_stream = None
+        self.bwd_streams: List = []
+        self._lanes_live = False          # True between begin_step and join_lanes of a graphed training step
+        self._f_done = {}
         self.reset()
 
     def reset(self) -> None:
@@ -148,6 +179,7 @@ class PipelineStage:
         self.grads_in: dict = {}
         self.losses: dict = {}
         self._cuts = {}
+        self._lanes_dirty = False
 
     # ---- P2P transfer builders -----------------------------------------------------------
     def _slot(self, table: dict, i: int, shape) -> torch.Tensor:
@@ -189,6 +221,7 @@ class PipelineStage:
         shape.  The first ``graph_warmup`` steps of a shape run eagerly, the next one captures every
         forward / backward in schedule order (capture + replay in place), later steps only replay."""
         self._gs = None
+        self._lanes_live = False
         if not self.hip_graph:
             return
         gs = self._graph_sets.get(signature)
@@ -196,14 +229,78 @@ class PipelineStage:
             gs = self._graph_sets[signature] = _GraphSet(self.graph_warmup)
         gs.begin_step()
         self._gs = gs if gs.active else None
+        train = bool(signature[1]) if len(signature) > 1 else False
+        if self._gs is not None and self.lanes_concurrent and train:
+            self._open_lanes()
+
+    # ---- lanes ---------------------------------------------------------------------------
+    def _open_lanes(self) -> None:
+        """Fork the lane streams from the compute stream: they start behind everything enqueued so far (input
+        copies, zero_grad, the previous step's Adam)."""
+        main = torch.cuda.current_stream(self.device)
+        if self.fwd_stream is None:
+            avoid = [main, getattr(self.module, "side_stream", None),
+                     getattr(self.dp_engine, "comm_stream", None), self.chan.stream]
+            self.fwd_stream = new_stream(self.device, avoid=avoid)
+            for _ in range(self.n_lanes):
+                self.bwd_streams.append(new_stream(self.device, avoid=avoid + [self.fwd_stream] + self.bwd_streams))
+        begin = torch.cuda.Event()
+        begin.record(main)
+        for st in [self.fwd_stream] + self.bwd_streams:
+            st.wait_event(begin)
+        self._f_done = {}
+        self._lanes_live = True
+
+    def stream_for(self, kind: str, i: int, last: bool = False):
+        """Stream micro-batch ``i``'s forward (``"F"``) / backward (``"B"``) runs on; None = the compute stream."""
+        if not self._lanes_live:
+            return None
+        if kind == "F":
+            return self.fwd_stream
+        if last and self.join_before_last:
+            return None
+        return self.bwd_streams[i % self.n_lanes]
+
+    def lane_ctx(self, stream):
+        return torch.cuda.stream(stream) if stream is not None else nullcontext()
+
+    def join_lanes(self) -> None:
+        """The compute stream waits for every lane; the gradient lanes are added into the arena (lane order).
+        Idempotent within a step."""
+        if self._lanes_live:
+            main = torch.cuda.current_stream(self.device)
+            for st in [self.fwd_stream] + self.bwd_streams:
+                done = torch.cuda.Event()
+                done.record(st)
+                main.wait_event(done)
+            self._lanes_live = False
+        if self.n_lanes > 1 and self._lanes_dirty:
+            self.module.sum_grad_lanes()
+            self._lanes_dirty = False
 
     def forward(self, i: int, x: Optional[torch.Tensor], target: Optional[torch.Tensor],
                 loss_fn, train: bool, last: bool = False) -> None:
-        with trace_range(f"Forward {i}"):          # the library's range names (schedules.py:757)
+        with trace_range(f"Forward {i}"), self.lane_ctx(self.stream_for("F", i)):      # range names: schedules.py:757
             self._forward(i, x, target, loss_fn, train, last)
+            if self._lanes_live:
+                self._f_done[i] = torch.cuda.Event()
+                self._f_done[i].record(self.fwd_stream)
+
+    def _grad_lane(self, i: int, last: bool) -> int:
+        """Gradient arena micro-batch ``i`` accumulates into."""
+        if self.n_lanes == 1 or (last and self.join_before_last):
+            return 0
+        return i % self.n_lanes
 
     def backward(self, i: int, scale: float, last: bool) -> None:
-        with trace_range(f"Backward {i}"):         # schedules.py:785
+        if last and self.join_before_last and self.n_lanes > 1:
+            # the reducer is armed for this backward only (ddp_n_pp.py:139 + torch stage.py:632-646): everything the
+            # earlier micro-batches accumulated must be in the arena before its first bucket leaves
+            self.join_lanes()
+        stream = self.stream_for("B", i, last)
+        with trace_range(f"Backward {i}"), self.lane_ctx(stream):                    # schedules.py:785
+            if stream is not None and i in self._f_done:
+                stream.wait_event(self._f_done[i])
             self._backward(i, scale, last)
 
     def _forward(self, i: int, x: Optional[torch.Tensor], target: Optional[torch.Tensor],
@@ -219,7 +316,8 @@ class PipelineStage:
             node.t = target.clone() if target is not None else None
             inp_slot = None if self.is_first else self.inputs[i]     # persistent receive slot
             node.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(node.graph, pool=gs.pool(), capture_error_mode="thread_local"):
+            with torch.cuda.graph(node.graph, pool=gs.pool("F" if self._lanes_live else None),
+                                  capture_error_mode="thread_local"):
                 if not self.is_first:
                     self.inputs[i] = inp_slot
                 self._forward_eager(i, node.x, node.t, loss_fn, train, phased)
@@ -242,24 +340,33 @@ class PipelineStage:
             return self._backward_eager(i, scale, last)
         dp = self.dp_engine
         node = gs.bwd.get(i)
-        mode = dict(pool=gs.pool(), capture_error_mode="thread_local")
+        lane = self._grad_lane(i, last)
+        # lanes: graphs of different backward streams replay concurrently -> one pool per stream, and the autograd
+        # graph is retained so that the saved activations (forward pool) are never handed to a later forward
+        # capture while this backward may still be reading them
+        lanes = self.n_lanes > 1 and self.lanes_concurrent
+        mode = dict(pool=gs.pool(("B", lane) if lanes else None), capture_error_mode="thread_local")
+        if self.n_lanes > 1:
+            self._lanes_dirty = self._lanes_dirty or lane > 0
         if node is None:
             node = gs.bwd[i] = _GraphNode()
             if dp is not None:
                 dp.arm(False)                      # no collectives inside a capture
+            if self.n_lanes > 1:
+                self.module.set_grad_lane(lane)    # the captured kernels write this lane's gradient arena
             grad_slot = self.grads_in.get(i)
             cuts = self._cuts.pop(i, None)         # phased forward of the last micro-batch (hybrid)
             node.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(node.graph, **mode):
                 if grad_slot is not None:
                     self.grads_in[i] = grad_slot
-                self._backward_eager(i, scale, False, arm=False, finish_input=not cuts)
+                self._backward_eager(i, scale, False, arm=False, finish_input=not cuts, retain=lanes, set_lane=False)
                 self._check_joined()
             if cuts:
                 for k, (y_mid, leaf) in enumerate(reversed(cuts)):        # one graph per earlier phase
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, **mode):
-                        y_mid.backward(leaf.grad)
+                        y_mid.backward(leaf.grad, retain_graph=lanes)
                         if k == len(cuts) - 1:
                             self._finish_input(i)
                         self._check_joined()
@@ -323,17 +430,25 @@ class PipelineStage:
         else:
             self.inputs.pop(i, None)
 
-    def _backward_eager(self, i: int, scale: float, last: bool, arm: bool = True, finish_input: bool = True) -> None:
+    def _backward_eager(self, i: int, scale: float, last: bool, arm: bool = True, finish_input: bool = True,
+                        retain: bool = False, set_lane: bool = True) -> None:
         dp = self.dp_engine
+        if self.n_lanes > 1 and set_lane:
+            # eager / --debug-sync: the same lane arithmetic as the graphed step, on one stream
+            if last and self.join_before_last:
+                self.join_lanes()
+            lane = self._grad_lane(i, last)
+            self.module.set_grad_lane(lane)
+            self._lanes_dirty = self._lanes_dirty or lane > 0
         if dp is not None and arm:
             dp.arm(last)
         if self.is_last:
             loss = self.losses[i]
-            (loss * scale).backward()
+            (loss * scale).backward(retain_graph=retain)
             self.outputs[i] = self.outputs[i].detach()
         else:
             # the 1/M factor entered at the loss on the last stage and rides the chain rule back
-            torch.autograd.backward(self.outputs.pop(i), grad_tensors=self.grads_in.pop(i))
+            torch.autograd.backward(self.outputs.pop(i), grad_tensors=self.grads_in.pop(i), retain_graph=retain)
         if finish_input:
             self._finish_input(i)
 
@@ -395,43 +510,57 @@ class _ScheduleBase:
     # ---- helpers -----------------------------------------------------------------------
     def _F(self, i, xs, ts, train):
         self.order.append(f"F{i}")
-        tok = self.profiler.begin("compute") if self.profiler else None
+        on = self._sf(i)
+        tok = self.profiler.begin("compute", on) if self.profiler else None
         self.stage.forward(i, xs[i], ts[i], self.loss_fn if train else None, train, last=(i == self.n - 1))
         if tok is not None:
-            self.profiler.end(tok)
+            self.profiler.end(tok, on)
 
     def _B(self, i):
         self.order.append(f"B{i}")
-        tok = self.profiler.begin("compute") if self.profiler else None
+        on = self._sb(i)
+        tok = self.profiler.begin("compute", on) if self.profiler else None
         scale = 1.0 / self.n if self.scale_grads else 1.0
         self.stage.backward(i, scale, last=(i == self.n - 1))
         if tok is not None:
-            self.profiler.end(tok)
+            self.profiler.end(tok, on)
 
-    def _post(self, sends=(), recvs=()):
-        """Issue one transfer group on the P2P channel; returns its ticket (None for an empty group)."""
-        return self.stage.chan.post(sends, recvs)
+    def _post(self, sends=(), recvs=(), on=None):
+        """Issue one transfer group on the P2P channel; returns its ticket (None for an empty group).  ``on``: the
+        stream that produced the payload of ``sends`` (lanes) - the group is fenced behind that stream; None = the
+        compute stream."""
+        with self.stage.lane_ctx(on):
+            return self.stage.chan.post(sends, recvs)
 
-    def _send(self, sends) -> None:
+    def _send(self, sends, on=None) -> None:
         """A pure send group: nobody on this rank waits for it before the end of the step."""
-        self._sends.append(self._post(sends=sends))
+        self._sends.append(self._post(sends=sends, on=on))
 
-    def _await(self, ticket) -> None:
-        """The compute stream waits for a group whose payload it is about to read ("p2p_wait" = how long it
-        actually stalled there)."""
+    def _await(self, ticket, on=None) -> None:
+        """The stream that is about to read a group's payload (``on``; None = the compute stream) waits for it
+        ("p2p_wait" = how long it actually stalled there)."""
         if ticket is None:
             return
-        tok = self.profiler.begin("p2p_wait") if self.profiler else None
-        self.stage.chan.wait(ticket)
-        if tok is not None:
-            self.profiler.end(tok)
+        with self.stage.lane_ctx(on):
+            tok = self.profiler.begin("p2p_wait") if self.profiler else None
+            self.stage.chan.wait(ticket)
+            if tok is not None:
+                self.profiler.end(tok)
+
+    def _sf(self, i: int):
+        return self.stage.stream_for("F", i)
+
+    def _sb(self, i: int):
+        return self.stage.stream_for("B", i, last=(i == self.n - 1))
 
     def _settle(self) -> None:
         """End of the step: the send buffers (graph outputs, gradient slots) are rewritten by the next step."""
+        self.stage.join_lanes()          # compute stream behind every lane; gradient lanes summed into the arena
         for t in self._sends:
             self.stage.chan.wait(t)
         self._sends = []
         self.stage.chan.drain()
+        self.stage.chan.fence()          # next step's pre-posted receives reuse this step's slots: behind their readers
 
     def _forward_phase(self, xs, ts, sizes, train, count: int, first: int = 0) -> None:
         """Forwards ``first .. first+count-1`` with the next activation's receive posted one micro-batch ahead
@@ -443,9 +572,9 @@ class _ScheduleBase:
         for i in range(first, first + count):
             if i + 1 < first + count:
                 tickets[i + 1] = self._post(recvs=st.fwd_recv(i + 1, sizes[i + 1]))
-            self._await(tickets.pop(i))
+            self._await(tickets.pop(i), on=self._sf(i))
             self._F(i, xs, ts, train)
-            self._send(st.fwd_send(i))
+            self._send(st.fwd_send(i), on=self._sf(i))
 
     def _backward_phase(self, first: int, count: int) -> None:
         st = self.stage
@@ -455,9 +584,9 @@ class _ScheduleBase:
         for i in range(first, first + count):
             if i + 1 < first + count:
                 tickets[i + 1] = self._post(recvs=st.bwd_recv(i + 1))
-            self._await(tickets.pop(i))
+            self._await(tickets.pop(i), on=self._sb(i))
             self._B(i)
-            self._send(st.bwd_send(i))
+            self._send(st.bwd_send(i), on=self._sb(i))
 
     def _run(self, xs, ts, sizes, train):
         raise NotImplementedError
@@ -490,29 +619,30 @@ class Schedule1F1B(_ScheduleBase):
         for f in range(warmup):
             if f + 1 < warmup:
                 tickets[f + 1] = self._post(recvs=st.fwd_recv(f + 1, sizes[f + 1]))
-            self._await(tickets.pop(f))
+            self._await(tickets.pop(f), on=self._sf(f))
             self._F(f, xs, ts, True)
             fwd_sends = st.fwd_send(f)
             if f != warmup - 1:
-                self._send(fwd_sends)
+                self._send(fwd_sends, on=self._sf(f))
                 fwd_sends = []
         f, b = warmup, 0
         # steady state: 1B1F
         while True:
-            # forward-send of the newest activation fused with the backward-recv (same peer: next)
-            self._await(self._post(sends=fwd_sends, recvs=st.bwd_recv(b)))
+            # forward-send of the newest activation fused with the backward-recv (same peer: next); with lanes the
+            # payload comes from the forward stream and the backward's stream waits for the group
+            self._await(self._post(sends=fwd_sends, recvs=st.bwd_recv(b), on=self._sf(f - 1)), on=self._sb(b))
             self._B(b)
             bwd_sends = st.bwd_send(b)
             b += 1
             if f == n:
                 break
             # backward-send fused with the next forward-recv (same peer: prev)
-            self._await(self._post(sends=bwd_sends, recvs=st.fwd_recv(f, sizes[f])))
+            self._await(self._post(sends=bwd_sends, recvs=st.fwd_recv(f, sizes[f]), on=self._sb(b - 1)), on=self._sf(f))
             self._F(f, xs, ts, True)
             fwd_sends = st.fwd_send(f)
             f += 1
         # cooldown: drain the remaining backwards (next gradient's receive posted one ahead)
-        self._send(bwd_sends)
+        self._send(bwd_sends, on=self._sb(b - 1))
         self._backward_phase(b, n - b)
 
 

@@ -194,6 +194,18 @@ class PPStrategy(Strategy):
         self.stage_index = mesh.pp_index
         self.split_points = list(cfg.split_points)
         self.unit_costs = None
+        # A resumed run rebuilds exactly the stages that were saved: snapshots are keyed model{stage} / optim{stage}
+        # (reference layout), so the resolved partition travels with the snapshot (checkpoint.save_partition)
+        saved = ckpt.load_partition(ckpt.resume_path(cfg.ckpt_subdir, job_id_from_env(), cfg.snapshot_job_id,
+                                                     cfg.snapshot_epoch, cfg.resume_latest))
+        if saved is not None:
+            if self.split_points == ["auto"]:
+                self.split_points = list(saved)
+                if ctx.rank == 0:
+                    print(f"[pp] resuming: stage boundaries taken from the snapshot: {self.split_points}", flush=True)
+            elif self.split_points != list(saved):
+                raise ValueError(f"--split-points {self.split_points} differ from the partition the snapshot was saved "
+                                 f"with ({saved}): its model{{stage}} / optim{{stage}} keys would not match the stages")
         if self.split_points == ["auto"]:
             # balance the stages on measured per-unit forward+backward time at this run's micro-batch size
             # (models/split.py); the reference's fixed split leaves 73 % of the work on stage 0
@@ -254,7 +266,7 @@ class PPStrategy(Strategy):
                                    group=mesh.get_group("pp"), ranks=mesh.pp_ranks,
                                    recv_shape_fn=recv_shape, dp_engine=self.dp,
                                    hip_graph=cfg.hip_graph and native and self.device.type == "cuda",
-                                   debug_sync=cfg.debug_sync, profiler=self.profiler)
+                                   debug_sync=cfg.debug_sync, profiler=self.profiler, n_lanes=cfg.pp_lanes)
         sched = SCHEDULES[cfg.schedule]
         # two schedules over one stage, like the reference (pp.py:138-150): training (with loss)
         # and loss-less inference for evaluation under no_grad
@@ -352,16 +364,11 @@ class Trainer:
         self._fault = tuple(int(v) for v in cfg.fault_inject.split(":")) if cfg.fault_inject else None
         self._trace = StepTrace(cfg.trace_dir, strategy.global_rank, cfg.trace_skip, cfg.trace_steps)
 
-        snap_job, snap_epoch = cfg.snapshot_job_id, cfg.snapshot_epoch
-        if cfg.resume_latest and snap_job is None:
-            latest = ckpt.latest_snapshot(cfg.ckpt_subdir, self.job_id)
-            if latest is not None:
-                snap_job, snap_epoch = self.job_id, latest
-        if snap_job is not None and snap_epoch is not None:
-            path = ckpt.snapshot_path(cfg.ckpt_subdir, snap_job, snap_epoch)
-            if os.path.exists(path):                               # single.py:115-119
-                self._print("Loading snapshot")
-                self._load_snapshot(path)
+        path = ckpt.resume_path(cfg.ckpt_subdir, self.job_id, cfg.snapshot_job_id, cfg.snapshot_epoch,
+                                cfg.resume_latest)                  # single.py:115-119
+        if path is not None:
+            self._print("Loading snapshot")
+            self._load_snapshot(path)
 
     # ---- plumbing ----------------------------------------------------------------------
     def _print(self, msg: str) -> None:
@@ -384,6 +391,8 @@ class Trainer:
             # de-duplicates the (identically keyed) optimizer state across the DP replicas
             dp.gather_sharded(opt.exp_avg, opt.exp_avg_sq)
         ckpt.save_snapshot(path, epoch, self.s.model, self.s.optimizer, self.s.ckpt_suffix)
+        if self.s.global_rank == 0 and getattr(self.s, "split_points", None) is not None:
+            ckpt.save_partition(path, self.s.split_points)         # the resolved stage boundaries (resume with auto)
         self._print(f"Epoch {epoch} | Saved snapshot to {path}")
 
     # ---- training ----------------------------------------------------------------------

@@ -113,22 +113,37 @@ def test_mesh_smoke_and_split_explorer(tmp_path):
     assert "Model parameters: 7978856" in out and "Total num params: 7978856" in out
 
 
+def _bench(n, args, tmp_path, env_extra=None, expect_rc=0):
+    env = dict(os.environ, DDL_LOG_DIR=str(tmp_path / "logs"), DDL_CKPT_DIR=str(tmp_path / "ckpt"),
+               DDL_DATA_DIR=str(tmp_path / "nodata"), OMP_NUM_THREADS="2", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    env.update(env_extra or {})
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+            "127.0.0.1", "--master-port", str(free_port()), "bench.py", "--gpus", str(n)] if n > 1 else
+           [sys.executable, "bench.py"])
+    r = subprocess.run(cmd + list(args), cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=900)
+    assert r.returncode == expect_rc, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    return r
+
+
 def test_bench_json_contract_cpu(tmp_path):
-    """bench.py prints ONE JSON line with the driver's fields; on CPU it runs the PyTorch stage over gloo (world 2)."""
-    env = dict(os.environ, OMP_NUM_THREADS="2")
-    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), "bench.py", "--gpus", "2",
-                        "--steps", "1", "--warmup", "0", "--batch-per-gpu", "2"],
-                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
+    """bench.py prints ONE JSON line with the driver's fields; on CPU it runs the PyTorch stage over gloo (world 2).
+    VERDICT r2 item 3: the line must say what actually ran - the first-contact ladder runs (and is listed), ``n_gpus``
+    counts distinct GPUs (none here), ``world`` / ``backend`` / ``ranks_per_device`` say the rest, and every DDL_*
+    switch that was set is listed."""
+    r = _bench(2, ["--steps", "1", "--warmup", "0", "--batch-per-gpu", "2", "--image-size", "32"], tmp_path,
+               env_extra={"DDL_TRACE": "0"})
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout
+    assert len(lines) == 1, r.stdout                                   # ONE JSON line, rank 0 only
     rec = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config"):
+              "vs_baseline", "dtype", "data", "config", "world", "backend", "distinct_devices", "ranks_per_device"):
         assert k in rec, k
-    assert rec["n_gpus"] == 2 and rec["steps"] == 1 and rec["warmup"] == 0 and rec["unit"] == "samples/s"
+    assert rec["steps"] == 1 and rec["warmup"] == 0 and rec["unit"] == "samples/s"
+    assert rec["n_gpus"] == 0 and rec["world"] == 2 and rec["backend"] == "gloo"
+    assert rec["distinct_devices"] == 1 and rec["ranks_per_device"] == 2 and rec["plumbing_run"] is True
     assert rec["higher_is_better"] is True and rec["scaling"] == "weak" and rec["dtype"] == "fp32"
     assert rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2"
     assert rec["value"] == pytest.approx(4 * 1 / (rec["ms_per_step"] / 1e3), rel=1e-3)
@@ -136,6 +151,11 @@ def test_bench_json_contract_cpu(tmp_path):
     # multi-rank runs return the tuning data in the same line: both collective forms and the bucket sweep
     assert set(rec["grad_sync_ab"]) == {"rs_ag", "allreduce"} and set(rec["bucket_mb_sweep"]) == {"8.0", "2.0", "32.0"}
     assert "extras" not in rec
+    assert {"barrier", "all-reduce"} <= set(rec["first_contact_ladder"])
+    assert any("reduce-scatter" in s for s in rec["first_contact_ladder"])
+    assert "DDL_TRACE=0" in rec["experimental_env"]
+    for stage in ("barrier", "all-reduce", "priming step 0 (eager)", "the 1 timed steps"):
+        assert f"stage '{stage}' ok" in r.stderr, r.stderr[-3000:]
 
 
 def test_bench_watchdog_keeps_the_headline_when_the_extras_hang(tmp_path):
@@ -145,13 +165,14 @@ def test_bench_watchdog_keeps_the_headline_when_the_extras_hang(tmp_path):
     env.pop("RANK", None), env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", str(free_port()), "bench.py", "--gpus", "2",
-                        "--steps", "1", "--warmup", "0", "--batch-per-gpu", "2", "--extras-timeout", "0.2"],
+                        "--steps", "1", "--warmup", "0", "--batch-per-gpu", "2", "--image-size", "32",
+                        "--extras-timeout", "0.2"],
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["value"] > 0 and "abandoned" in rec["extras"] and "grad_sync_ab" not in rec
+    assert rec["world"] == 2 and rec["value"] > 0 and "abandoned" in rec["extras"] and "grad_sync_ab" not in rec
 
 
 def test_rank_failure_aborts_job_and_resume_latest_recovers(tmp_path):
@@ -171,3 +192,42 @@ def test_rank_failure_aborts_job_and_resume_latest_recovers(tmp_path):
     out = _torchrun(2, "ddp.py", [*args, "--resume-latest"], env)
     assert "Resuming training from snapshot at Epoch 1" in out and "Starting Epoch 0" not in out
     assert "Epoch 2 | Saved snapshot" in out
+
+
+def test_bench_refuses_wrong_result_switches_and_names_a_hung_stage(tmp_path):
+    """DDL_KNOCKOUT (kernels left out of the step) is refused outright; a stage that exceeds its time limit makes the
+    run name the stage and exit 4 (here: a 2-rank launch where the ladder's time limit is too short to pass)."""
+    r = _bench(1, ["--steps", "1", "--warmup", "0", "--batch-per-gpu", "2", "--image-size", "32"], tmp_path,
+               env_extra={"DDL_KNOCKOUT": "wgrad"}, expect_rc=5)
+    assert "refusing to run with DDL_KNOCKOUT=wgrad" in r.stderr and "{" not in r.stdout
+    from ddl import diagnostics
+    code = ("import sys, time; sys.path.insert(0, %r); from ddl import diagnostics as d\n"
+            "wd = d.StageWatchdog(0, 'probe', exit_code=4)\n"
+            "with wd.stage('quick', 5): pass\n"
+            "with wd.stage('stuck collective', 0.3): time.sleep(30)\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 4, (p.returncode, p.stderr)
+    assert "STAGE 'stuck collective' did not complete" in p.stderr and "completed before it: ['quick']" in p.stderr
+    assert diagnostics.experimental_env() == sorted(f"{k}={v}" for k, v in os.environ.items()
+                                                    if k.startswith("DDL_") and k not in diagnostics._BENIGN_ENV)
+
+
+def test_pp_resume_rebuilds_the_saved_partition(tmp_path):
+    """snapshots are keyed model{stage} / optim{stage}, so a resumed pipeline must rebuild the stages that
+    were saved.  The resolved stage boundaries travel with the snapshot (partition.json): `--split-points auto` on
+    resume reuses them instead of re-deriving a split (here the saved cut is one auto would never choose), and an
+    explicit split that differs from the saved one is refused with a clear message."""
+    env = _env(tmp_path)
+    cut = "features.denseblock2.denselayer5"
+    out = _torchrun(2, "pp.py", [*SMALL, "--batch-size", "10", "--split-points", cut, "--save-every", "1"], env)
+    snap = tmp_path / "ckpt" / "pp" / "job-123" / "epoch_0"
+    assert "Saved snapshot" in out and json.load(open(snap / "partition.json"))["split_points"] == [cut]
+    out = _torchrun(2, "pp.py", [*SMALL[2:], "--epochs", "2", "--batch-size", "10", "--split-points", "auto",
+                                 "--resume-latest"], env)
+    assert f"stage boundaries taken from the snapshot: ['{cut}']" in out
+    assert "Resuming training from snapshot at Epoch 1" in out and "Starting Epoch 1" in out
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), "pp.py", *SMALL[2:], "--epochs",
+                        "2", "--batch-size", "10", "--resume-latest"],          # default split = denseblock3
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=420)
+    assert r.returncode != 0 and "differ from the partition the snapshot was saved with" in r.stdout

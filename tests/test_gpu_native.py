@@ -376,6 +376,7 @@ def test_bn_backward_handoff_equals_the_explicit_pass(dev, monkeypatch):
     ref = _ref_stage(units, dev)
     stages = {}
     for flag in ("1", "0"):
+        monkeypatch.setenv("DDL_EXPERIMENTAL", "1")       # experiment switches are ignored without it (utils/knobs.py)
         monkeypatch.setenv("DDL_DEFER_AFFINE", flag)
         stages[flag] = _native_from(ref, units, dev)
         stages[flag].train()
