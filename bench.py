@@ -91,6 +91,7 @@ def main() -> None:
                     help="first-contact ladder before anything is built (auto: when W>1 or DDL_FORCE_COLLECTIVES=1)")
     ap.add_argument("--stage-timeout", type=float, default=180.0,
                     help="seconds one first-contact / priming stage may take before the run names it and exits 4")
+    ap.add_argument("--fwd-lanes", type=int, default=None, help="pipeline modes: forward streams (TrainConfig.pp_fwd_lanes)")
     ap.add_argument("--lanes", type=int, default=None, help="pipeline modes: concurrent micro-batch lanes per stage "
                                                             "(default: TrainConfig.pp_lanes)")
     ap.add_argument("--zero1", action="store_true")
@@ -170,6 +171,7 @@ def main() -> None:
                           sync_buffers=a.sync_buffers, num_workers=0,
                           **({} if gp is None else {"grad_phases": gp}),
                           **({} if a.lanes is None else {"pp_lanes": a.lanes}),
+                          **({} if a.fwd_lanes is None else {"pp_fwd_lanes": a.fwd_lanes}),
                           **({} if (a.grad_sync is None or tune_grad_sync) else {"grad_sync": a.grad_sync}))
         return build_strategy(cfg, ctx)
 
@@ -379,7 +381,8 @@ def main() -> None:
     if pipeline:
         out["config"].update(preset=a.preset, microbatches=n_mb, schedule=a.schedule,
                              split_points=list(getattr(strat, "split_points", split)),
-                             lanes=getattr(getattr(strat, "stage", None), "n_lanes", 1))
+                             lanes=getattr(getattr(strat, "stage", None), "n_lanes", 1),
+                             fwd_lanes=getattr(getattr(strat, "stage", None), "n_fwd", 1))
     if ladder:
         out["first_contact_ladder"] = ladder          # rungs that completed (value-checked) before anything was built
     if grad_sync_tuned is not None:

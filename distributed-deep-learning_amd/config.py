@@ -67,8 +67,10 @@ class TrainConfig:
     # ---- pipeline parallel (reference: pp.py:378-386) ------------------------
     num_microbatches: int = 5
     schedule: str = "1f1b"              # 1f1b | gpipe
-    pp_lanes: int = 1                   # concurrent micro-batch lanes per stage (parallel/pp.py "lanes"): backward of
+    pp_lanes: int = 2                   # concurrent micro-batch lanes per stage (parallel/pp.py "lanes"): backward of
     #                                     micro-batch i next to the forward of i+k on separate streams / graph pools
+    pp_fwd_lanes: int = 2               # forward streams when pp_lanes > 1 (BN running statistics handed off in
+    #                                     micro-batch order through per-micro-batch scratch copies)
     split_points: List[str] = field(default_factory=lambda: ["features.denseblock3.denselayer1"])
     # ---- 2-D mesh (reference: ddp_n_pp.py:32-33) -----------------------------
     dp_size: int = 0                    # 0: world_size // pp_size

@@ -692,11 +692,18 @@ class NativeDenseNetStage(nn.Module):
         # steps only, never on the replay path).
         self._grad_lanes: List[torch.Tensor] = [self.arena.flat_grad]
         self._grad_lane = 0
+        # buffer lanes (forward lanes): lane 0 is the real running statistics; lane 1 + i is micro-batch i's scratch
+        # copy - forwards that run concurrently leave `momentum * statistic` there (the kernels' update applied to
+        # zeros) and the running statistics are advanced in micro-batch order afterwards (``combine_buffer_lanes``)
+        self._buf_lanes: List[torch.Tensor] = [self.flat_buffers.flat_float]
+        self._buf_lane = 0
+        self.defer_counters = False       # num_batches_tracked advanced by combine_buffer_lanes instead of per forward
+        self._mb_forwarded = set()
         for u in self.unit_objs:
             before = dict(vars(u))
             u.bind()
             u._bind_keys = [k for k, v in vars(u).items() if k not in before or before[k] is not v]
-            u._lane_cache = {0: {k: getattr(u, k) for k in u._bind_keys}}
+            u._lane_cache = {(0, 0): {k: getattr(u, k) for k in u._bind_keys}}
 
     def unit_of_param(self, fqn: str) -> str:
         """Unit of this stage that owns a parameter (torchvision FQN)."""
@@ -763,16 +770,19 @@ class NativeDenseNetStage(nn.Module):
 
     def set_grad_lane(self, k: int) -> None:
         """Kernels launched (or captured) from now on accumulate parameter gradients into gradient lane ``k``."""
-        if k == self._grad_lane:
-            return
         if not 0 <= k < len(self._grad_lanes):
             raise ValueError(f"gradient lane {k} of {len(self._grad_lanes)}")
-        self._grad_lane = k
+        self._set_lanes(k, self._buf_lane)
+
+    def _set_lanes(self, g: int, b: int) -> None:
+        if (g, b) == (self._grad_lane, self._buf_lane):
+            return
+        self._grad_lane, self._buf_lane = g, b
         for u in self.unit_objs:
-            cached = u._lane_cache.get(k)
+            cached = u._lane_cache.get((g, b))
             if cached is None:
                 u.bind()
-                cached = u._lane_cache[k] = {key: getattr(u, key) for key in u._bind_keys}
+                cached = u._lane_cache[(g, b)] = {key: getattr(u, key) for key in u._bind_keys}
             else:
                 for key, val in cached.items():
                     setattr(u, key, val)
@@ -784,8 +794,40 @@ class NativeDenseNetStage(nn.Module):
             lane.zero_()
         self.set_grad_lane(0)
 
+    # ---- buffer lanes (concurrent forwards) ---------------------------------------------------
+    def ensure_buffer_lanes(self, n_microbatches: int) -> None:
+        while len(self._buf_lanes) < 1 + n_microbatches:
+            self._buf_lanes.append(torch.zeros_like(self.flat_buffers.flat_float))
+        self.defer_counters = True
+
+    def begin_microbatch_buffers(self, i: int) -> None:
+        """Training forward of micro-batch ``i`` is next (eager, or being captured): its BN kernels update scratch
+        copy ``i`` (cleared here - inside the graph when capturing) instead of the running statistics."""
+        self._buf_lanes[1 + i].zero_()
+        self._set_lanes(self._grad_lane, 1 + i)
+        self._mb_forwarded.add(i)
+
+    def note_microbatch_forward(self, i: int) -> None:
+        """Replay path: micro-batch ``i``'s captured forward was launched (its scratch copy will hold an update)."""
+        self._mb_forwarded.add(i)
+
+    def combine_buffer_lanes(self) -> None:
+        """running = (1 - momentum) * running + scratch_i, in micro-batch order, for the forwards of this step; the
+        num_batches_tracked counters advance by their number.  Runs on the compute stream after the lanes joined."""
+        ff = self.flat_buffers.flat_float
+        keep = float(torch.tensor(1.0) - torch.tensor(BN_MOMENTUM, dtype=torch.float32))    # the kernels' (1.f - momentum)
+        for i in sorted(self._mb_forwarded):
+            ff.mul_(keep).add_(self._buf_lanes[1 + i])
+        if self._mb_forwarded and self.flat_buffers.flat_int.numel():
+            self.flat_buffers.flat_int.add_(len(self._mb_forwarded))
+        self._mb_forwarded = set()
+        self._set_lanes(self._grad_lane, 0)
+
     def bv(self, fqn: str) -> torch.Tensor:
-        return self._buffers_by_name[fqn]
+        if self._buf_lane == 0:
+            return self._buffers_by_name[fqn]
+        off, n, shape = self.flat_buffers.float_slots[fqn]
+        return self._buf_lanes[self._buf_lane][off:off + n].view(shape)
 
     # ---- BN backward of a transition / head handed to the dense block in front of it ---------------------------
     def set_pending_affine(self, producer, k1: torch.Tensor, k2: torch.Tensor) -> None:
@@ -904,7 +946,7 @@ class NativeDenseNetStage(nn.Module):
 
     def _bump_counters(self) -> None:
         fi = self.flat_buffers.flat_int
-        if fi.numel() == 0:
+        if fi.numel() == 0 or (self.defer_counters and self._buf_lane != 0):
             return
         fi.add_(1)
 

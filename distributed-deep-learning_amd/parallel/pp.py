@@ -58,7 +58,8 @@ from typing import Callable, List, Optional, Sequence, Tuple
 import torch
 
 from .p2p import P2PChannel, Transfer
-from ..utils.streams import new_stream
+from ..utils.knobs import knob
+from ..utils.streams import concurrent_streams
 from ..utils.trace import trace_range
 
 
@@ -132,7 +133,8 @@ class PipelineStage:
                  group=None, ranks: Optional[Sequence[int]] = None,
                  recv_shape_fn: Optional[Callable[[int], Tuple[int, ...]]] = None,
                  dtype: torch.dtype = torch.float32, dp_engine=None, hip_graph: bool = False,
-                 graph_warmup: int = 2, debug_sync: bool = False, profiler=None, n_lanes: int = 1) -> None:
+                 graph_warmup: int = 2, debug_sync: bool = False, profiler=None, n_lanes: int = 1,
+                 n_fwd_lanes: int = 1) -> None:
         self.module = module
         self.stage_index = stage_index
         self.num_stages = num_stages
@@ -166,8 +168,17 @@ class PipelineStage:
         if self.n_lanes > 1:
             module.ensure_grad_lanes(self.n_lanes)
         self.lanes_concurrent = self.hip_graph and self.n_lanes > 1 and not debug_sync
+        # With lanes every micro-batch graph is ONE chain: the weight-gradient side branch inside a graph runs on
+        # runtime-internal streams that all graphs share, which serialised B_i with B_{i+1} and F_{i+2} in the trace
+        # (profiles/r3/lane_timeline_*.txt: 20.1 ms per step with the fork, 15.4 without) - the lanes supply the
+        # concurrency.  DDL_LANE_WGRAD_FORK=1 (experiment switch) keeps the fork.
+        if self.lanes_concurrent and knob("DDL_LANE_WGRAD_FORK", "0") == "0" and hasattr(module, "overlap_wgrad"):
+            module.overlap_wgrad = False
         self.join_before_last = dp_engine is not None and not dp_engine.single
-        self.fwd_stream = None
+        # forward lanes: forward i on forward stream i % n_fwd, BN running statistics handed off in micro-batch order
+        # through per-micro-batch scratch copies (native_densenet "buffer lanes"); arithmetic applies in eager steps too
+        self.n_fwd = max(1, int(n_fwd_lanes)) if (self.n_lanes > 1 and hasattr(module, "ensure_buffer_lanes")) else 1
+        self.fwd_streams: List = []
         self.bwd_streams: List = []
         self._lanes_live = False          # True between begin_step and join_lanes of a graphed training step
         self._f_done = {}
@@ -233,20 +244,27 @@ class PipelineStage:
         if self._gs is not None and self.lanes_concurrent and train:
             self._open_lanes()
 
+    def prepare_step(self, n_microbatches: int, train: bool) -> None:
+        """Called by the schedule before ``begin_step`` (eager and graphed steps alike)."""
+        self._handoff = self.n_fwd > 1 and train
+        if self._handoff:
+            self.module.ensure_buffer_lanes(n_microbatches)
+
     # ---- lanes ---------------------------------------------------------------------------
     def _open_lanes(self) -> None:
         """Fork the lane streams from the compute stream: they start behind everything enqueued so far (input
         copies, zero_grad, the previous step's Adam)."""
         main = torch.cuda.current_stream(self.device)
-        if self.fwd_stream is None:
+        if not self.fwd_streams:
+            # streams on DISTINCT hardware queues (measured, utils/streams.py): two lanes that share a queue are
+            # serialised on the device whatever the events say
             avoid = [main, getattr(self.module, "side_stream", None),
                      getattr(self.dp_engine, "comm_stream", None), self.chan.stream]
-            self.fwd_stream = new_stream(self.device, avoid=avoid)
-            for _ in range(self.n_lanes):
-                self.bwd_streams.append(new_stream(self.device, avoid=avoid + [self.fwd_stream] + self.bwd_streams))
+            lanes = concurrent_streams(self.device, self.n_fwd + self.n_lanes, avoid=avoid)
+            self.fwd_streams, self.bwd_streams = lanes[:self.n_fwd], lanes[self.n_fwd:]
         begin = torch.cuda.Event()
         begin.record(main)
-        for st in [self.fwd_stream] + self.bwd_streams:
+        for st in self.fwd_streams + self.bwd_streams:
             st.wait_event(begin)
         self._f_done = {}
         self._lanes_live = True
@@ -256,7 +274,7 @@ class PipelineStage:
         if not self._lanes_live:
             return None
         if kind == "F":
-            return self.fwd_stream
+            return self.fwd_streams[i % self.n_fwd]
         if last and self.join_before_last:
             return None
         return self.bwd_streams[i % self.n_lanes]
@@ -269,7 +287,7 @@ class PipelineStage:
         Idempotent within a step."""
         if self._lanes_live:
             main = torch.cuda.current_stream(self.device)
-            for st in [self.fwd_stream] + self.bwd_streams:
+            for st in self.fwd_streams + self.bwd_streams:
                 done = torch.cuda.Event()
                 done.record(st)
                 main.wait_event(done)
@@ -277,6 +295,8 @@ class PipelineStage:
         if self.n_lanes > 1 and self._lanes_dirty:
             self.module.sum_grad_lanes()
             self._lanes_dirty = False
+        if getattr(self, "_handoff", False):
+            self.module.combine_buffer_lanes()       # running statistics advanced in micro-batch order
 
     def forward(self, i: int, x: Optional[torch.Tensor], target: Optional[torch.Tensor],
                 loss_fn, train: bool, last: bool = False) -> None:
@@ -284,7 +304,7 @@ class PipelineStage:
             self._forward(i, x, target, loss_fn, train, last)
             if self._lanes_live:
                 self._f_done[i] = torch.cuda.Event()
-                self._f_done[i].record(self.fwd_stream)
+                self._f_done[i].record(self.fwd_streams[i % self.n_fwd])
 
     def _grad_lane(self, i: int, last: bool) -> int:
         """Gradient arena micro-batch ``i`` accumulates into."""
@@ -316,7 +336,7 @@ class PipelineStage:
             node.t = target.clone() if target is not None else None
             inp_slot = None if self.is_first else self.inputs[i]     # persistent receive slot
             node.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(node.graph, pool=gs.pool("F" if self._lanes_live else None),
+            with torch.cuda.graph(node.graph, pool=gs.pool(("F", i % self.n_fwd) if self._lanes_live else None),
                                   capture_error_mode="thread_local"):
                 if not self.is_first:
                     self.inputs[i] = inp_slot
@@ -327,6 +347,8 @@ class PipelineStage:
                 node.x.copy_(x, non_blocking=True)
             if node.t is not None:
                 node.t.copy_(target, non_blocking=True)
+            if train and getattr(self, "_handoff", False):
+                self.module.note_microbatch_forward(i)
         node.graph.replay()
         if not self.is_first:
             self.inputs[i] = node.inp
@@ -414,6 +436,8 @@ class PipelineStage:
             if train:
                 inp.requires_grad_(True)
             self.inputs[i] = inp
+        if train and getattr(self, "_handoff", False):
+            self.module.begin_microbatch_buffers(i)      # BN running-statistic updates of this forward -> scratch i
         if phased:
             out, self._cuts[i] = self.module.forward_phased(inp)
         else:
@@ -492,6 +516,7 @@ class _ScheduleBase:
             raise RuntimeError("a schedule with a loss_fn cannot run under no_grad; "
                                "use a loss-less schedule for inference")
         st.reset()
+        st.prepare_step(self.n, train)
         st.begin_step((tuple(sizes), train, self.loss_fn is not None,
                        tuple(x.shape[1:]) if x is not None else None))
         self.order = []

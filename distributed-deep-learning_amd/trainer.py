@@ -266,7 +266,8 @@ class PPStrategy(Strategy):
                                    group=mesh.get_group("pp"), ranks=mesh.pp_ranks,
                                    recv_shape_fn=recv_shape, dp_engine=self.dp,
                                    hip_graph=cfg.hip_graph and native and self.device.type == "cuda",
-                                   debug_sync=cfg.debug_sync, profiler=self.profiler, n_lanes=cfg.pp_lanes)
+                                   debug_sync=cfg.debug_sync, profiler=self.profiler, n_lanes=cfg.pp_lanes,
+                                   n_fwd_lanes=cfg.pp_fwd_lanes)
         sched = SCHEDULES[cfg.schedule]
         # two schedules over one stage, like the reference (pp.py:138-150): training (with loss)
         # and loss-less inference for evaluation under no_grad

@@ -149,11 +149,13 @@ class FlatBuffers:
         self.flat_float = torch.zeros(sum(b.numel() for _, b in f), dtype=torch.float32, device=dev)
         self.flat_int = torch.zeros(sum(b.numel() for _, b in i), dtype=torch.int64, device=dev)
         off = 0
+        self.float_slots = {}            # name -> (offset, numel, shape) inside flat_float
         with torch.no_grad():
-            for _, b in f:
+            for n, b in f:
                 v = self.flat_float[off:off + b.numel()].view(b.shape)
                 v.copy_(b)
                 b.data = v
+                self.float_slots[n] = (off, b.numel(), tuple(b.shape))
                 off += b.numel()
             off = 0
             for _, b in i:
