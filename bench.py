@@ -79,9 +79,13 @@ def main() -> None:
     ap.add_argument("--split-points", nargs="+", default=None,
                     help="stage starts (reference module names) or 'auto' (balance on measured unit times)")
     ap.add_argument("--bucket-mb", type=float, default=8.0)
-    ap.add_argument("--grad-sync", choices=["rs_ag", "allreduce", "auto"], default=None,
-                    help="per-bucket collective (default: TrainConfig.grad_sync; auto = time both on the captured step "
-                         "during priming and keep the faster one - all ranks agree through a max-reduce)")
+    ap.add_argument("--grad-sync", choices=["rs_ag", "allreduce", "auto", "tune"], default=None,
+                    help="per-bucket collective (default: TrainConfig.grad_sync = auto: all-reduce for 2 ranks, rs_ag from "
+                         "3 on; tune = time both on the captured step during priming and keep the faster one - all "
+                         "ranks agree through a max-reduce)")
+    ap.add_argument("--rccl", choices=["auto", "direct", "c10d"], default="auto",
+                    help="RCCL transport of the bucket reducer and the pipeline P2P engine: owned communicators on the "
+                         "engines' own streams (csrc/rccl_comm.cpp) or c10d's process group")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="ddp mode: weak = 30 images per GPU (default), strong = the reference's GLOBAL batch of 30 "
                          "split over the ranks (ddp.py:335: 15 per rank at W=2)")
@@ -160,7 +164,7 @@ def main() -> None:
     else:
         split = default_split_points(max(pp_size, 1))
 
-    tune_grad_sync = a.grad_sync == "auto"
+    tune_grad_sync = a.grad_sync == "tune"
 
     def make_strategy(bucket_mb: float, grad_phases=None):
         gp = a.grad_phases if grad_phases is None else grad_phases
@@ -168,7 +172,7 @@ def main() -> None:
                           bucket_mb=bucket_mb, zero1=a.zero1, hip_graph=not a.no_graph,
                           num_microbatches=n_mb, schedule=a.schedule, pp_size=pp_size,
                           split_points=split, profile=a.profile,
-                          sync_buffers=a.sync_buffers, num_workers=0,
+                          sync_buffers=a.sync_buffers, num_workers=0, rccl=a.rccl,
                           **({} if gp is None else {"grad_phases": gp}),
                           **({} if a.lanes is None else {"pp_lanes": a.lanes}),
                           **({} if a.fwd_lanes is None else {"pp_fwd_lanes": a.fwd_lanes}),
@@ -191,7 +195,7 @@ def main() -> None:
             print(f"[rank 0] bench.py: world {topo['world']} over {topo['backend']}, {topo['distinct_devices']} distinct "
                   f"device(s), {topo['ranks_per_device']} rank(s) per device: {topo['device_ids']}", file=sys.stderr, flush=True)
         ladder_on = a.ladder == "on" or (a.ladder == "auto" and (world > 1 or comm.force_collectives()))
-        ladder = diagnostics.first_contact_ladder(ctx, pipeline, wd, a.stage_timeout) if ladder_on else []
+        ladder = diagnostics.first_contact_ladder(ctx, pipeline, wd, a.stage_timeout, rccl=a.rccl) if ladder_on else []
     except BaseException as e:      # noqa: BLE001
         fail("the first-contact ladder", e)
 
@@ -374,6 +378,8 @@ def main() -> None:
                           else "bucketed reduce-scatter + all-gather"),
             "bucket_mb": a.bucket_mb,
             "reducer": ("native" if getattr(engine, "_native", None) is not None else "python"),
+            "rccl_transport": {"reducer": getattr(engine, "transport", None),
+                               "p2p": getattr(getattr(getattr(strat, "stage", None), "chan", None), "transport", None)},
             "host_issue_ms_per_step": round(host_ms, 3),
             "peak_mem_gib": (round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2) if dev.type == "cuda" else None),
         },

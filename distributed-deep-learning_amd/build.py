@@ -97,6 +97,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         _run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-o", str(OUT),
               *[str(o) for o in objs], f"-L{tlib}", f"-Wl,-rpath,{tlib}",
               "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python",
+              "-lrccl",        # the RCCL that PyTorch itself loads (torch/lib/librccl.so): csrc/rccl_comm.cpp
               "-lz"])          # zlib: csrc/png_loader.cpp
         if verbose:
             print(f"[ddl.build] linked {OUT}", flush=True)

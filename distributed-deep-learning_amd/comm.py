@@ -87,6 +87,12 @@ def init(backend: str = "auto", device: str = "auto", timeout_s: int = 600,
 
 
 def destroy() -> None:
+    for c in _DIRECT.values():          # owned communicators first (their teardown is collective over the members)
+        try:
+            c.destroy()
+        except Exception:      # noqa: BLE001 - a peer that already left must not turn teardown into an error
+            c.abort()
+    _DIRECT.clear()
     if dist.is_initialized():
         dist.destroy_process_group()
 
@@ -111,6 +117,67 @@ def get_world_size(group=None) -> int:
 
 def backend_of(group=None) -> str:
     return dist.get_backend(group) if is_dist() else "none"
+
+
+# --------------------------------------------------------------------------------------
+# owned RCCL communicators (csrc/rccl_comm.cpp)
+# --------------------------------------------------------------------------------------
+_DIRECT: dict = {}
+_DIRECT_SEQ: dict = {}
+
+
+def rccl_transport(requested: str = "auto") -> str:
+    """``direct`` (owned communicators: RCCL enqueued on the engines' own HIP streams) or ``c10d`` (through the
+    process group).  ``auto`` = direct whenever the native extension is loaded; ``DDL_RCCL`` overrides (recorded
+    by ``bench.py`` like every other switch)."""
+    want = os.environ.get("DDL_RCCL", requested)
+    if want not in ("auto", "direct", "c10d"):
+        raise ValueError(f"rccl transport must be auto | direct | c10d, got {want!r}")
+    if want == "auto":
+        from . import ops
+        return "direct" if ops.have_ext() else "c10d"
+    return want
+
+
+def group_ranks(group=None) -> List[int]:
+    """Global ranks of a group's members, in group-rank order."""
+    if not is_dist():
+        return [0]
+    return list(range(dist.get_world_size())) if group is None else list(dist.get_process_group_ranks(group))
+
+
+def direct_comm(ranks, device: torch.device, tag: str = "world", fresh: bool = False):
+    """One owned RCCL communicator over the GLOBAL ranks ``ranks`` (member order = communicator rank order).
+
+    Collective over exactly those members: member 0 generates the unique id and publishes it through the c10d
+    store (the rendezvous every rank already shares), the others block on the key, then everybody joins
+    ``ncclCommInitRank``.  Communicators are cached per (tag, ranks): engines that are rebuilt (bench.py's bucket
+    sweep) reuse them, and every member derives the same store key from its own creation count.  Reference: the
+    communicators c10d creates lazily behind ``init_process_group('nccl')`` (ddp.py:29) and ``new_group`` /
+    ``init_device_mesh`` (ddp_n_pp.py:32-33)."""
+    from . import ops
+    ranks = [int(r) for r in ranks]
+    me = get_rank()
+    if me not in ranks:
+        raise ValueError(f"rank {me} is not a member of {ranks}")
+    key = (tag, tuple(ranks))
+    if not fresh and key in _DIRECT:
+        return _DIRECT[key]
+    ext = ops.require_ext()
+    seq = _DIRECT_SEQ.get(key, 0)
+    _DIRECT_SEQ[key] = seq + 1
+    store = dist.distributed_c10d._get_default_store()
+    skey = f"ddl/rccl_uid/{tag}/{'-'.join(map(str, ranks))}/{seq}"
+    if ranks.index(me) == 0:
+        uid = ext.rccl_unique_id()
+        store.set(skey, uid)
+    else:
+        uid = store.get(skey)                      # blocks (store timeout) until member 0 has published it
+    dev_index = device.index if device.index is not None else torch.cuda.current_device()
+    c = ext.RcclComm(bytes(uid), ranks.index(me), len(ranks), int(dev_index))
+    if not fresh:
+        _DIRECT[key] = c
+    return c
 
 
 # --------------------------------------------------------------------------------------

@@ -58,9 +58,15 @@ class TrainConfig:
     #   ^ torchvision densenet121 state-dict file (reference: weights=IMAGENET1K_V1, single.py:297)
     # ---- data parallel -------------------------------------------------------
     bucket_mb: float = 8.0              # gradient bucket size (MiB); sized for xGMI, not NVSwitch
-    grad_sync: str = "rs_ag"            # rs_ag (reduce-scatter + all-gather: both run directly over all 7 xGMI links of a
+    grad_sync: str = "auto"             # rs_ag (reduce-scatter + all-gather: both run directly over all 7 xGMI links of a
     #                                     fully connected node; the north-star form, also what --zero1 needs) | allreduce
-    #                                     (one RCCL launch per bucket).  bench.py at W>1 times both ("grad_sync_ab").
+    #                                     (one RCCL launch per bucket, what the reference's DDP does) | auto: allreduce
+    #                                     for a dp group of 2 (two launches cannot beat one over a single link), rs_ag
+    #                                     from 3 ranks on.  No multi-GPU measurement backs either choice yet ("parity
+    #                                     unpinned"): bench.py at W>1 times both on the same step ("grad_sync_ab") and
+    #                                     `--grad-sync tune` keeps the faster one.
+    rccl: str = "auto"                  # auto | direct | c10d: owned RCCL communicators enqueued on the engines' own HIP
+    #                                     streams (csrc/rccl_comm.cpp) vs. everything through c10d's process group
     zero1: bool = False                 # shard the Adam step over the dp group (RS grads, AG params)
     sync_buffers: str = "forward"       # forward (DDP parity) | epoch | off
     grad_phases: str = "denseblock3,denseblock2"   # units that open a new backward graph phase (DP overlap)

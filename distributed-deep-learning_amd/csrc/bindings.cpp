@@ -85,6 +85,20 @@ void register_stem_ops(pybind11::module_& m);   // stem_bindings.cpp
 void register_reducer(pybind11::module_& m);    // reducer.cpp
 void register_p2p(pybind11::module_& m);        // p2p.cpp
 void register_io(pybind11::module_& m);         // png_loader.cpp
+void register_rccl(pybind11::module_& m);       // rccl_comm.cpp
+
+// fence-test helpers (tests/test_gpu_fences.py): busy-wait on / scale a tensor on the current stream
+void test_spin(double micros, int64_t device_index) {
+  TORCH_CHECK(micros >= 0 && micros <= 2e6, "test_spin: at most 2 s");
+  ddl::DeviceGuard guard(c10::Device(c10::kCUDA, (c10::DeviceIndex)device_index));
+  ddl::launch_spin(micros, ddl::cur_stream());
+}
+
+void test_scale(at::Tensor t, double a) {
+  DDL_CHECK_DEV(t); DDL_CHECK_CONTIG(t); DDL_CHECK_F32(t);
+  ddl::DeviceGuard guard(t.device());
+  ddl::launch_scale(t.data_ptr<float>(), t.numel(), (float)a, ddl::cur_stream());
+}
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "hand-written gfx950 (MI355X) kernels of the ddl framework";
@@ -92,9 +106,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("ce_fwd_bwd", &ce_fwd_bwd, "fused softmax+CE loss, dlogits, argmax");
   m.def("adam_step", &adam_step, "flat fused Adam (+zero_grad)");
   m.def("copy_pair", &copy_pair, "two device-to-device copies in one launch");
+  register_rccl(m);          // first: RcclComm is a default-argument type of the reducer / P2P engine bindings
   register_conv_ops(m);
   register_stem_ops(m);
   register_reducer(m);
   register_p2p(m);
   register_io(m);
+  m.def("test_spin", &test_spin, "busy-wait `micros` on the current stream (bounded; fence tests)");
+  m.def("test_scale", &test_scale, "t *= a on the current stream (fence tests)");
 }

@@ -40,6 +40,9 @@ void launch_adam_inc_step(float* step_t, float* aux /*[2]: 1-b1^t, 1/sqrt(1-b2^t
 void launch_adam_flat(float* p, float* g, float* m, float* v, const float* aux, int64_t start,
                       int64_t end, double lr, double b1, double b2, double eps, double wd, bool zero_grad,
                       hipStream_t s);
+// fence-test helpers: busy-wait for `micros` on the stream (bounded), p[0:n] *= a
+void launch_spin(double micros, hipStream_t s);
+void launch_scale(float* p, long n, float a, hipStream_t s);
 
 }  // namespace ddl
 

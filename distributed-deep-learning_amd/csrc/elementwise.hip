@@ -64,8 +64,8 @@ __global__ void __launch_bounds__(1024) ce_fwd_bwd_kernel(const float* __restric
       if (v > mx) { mx = v; arg = c; }
     }
     float sum = 0.f;
-    for (int c = 0; c < C; ++c) sum += __expf(z[c] - mx);
-    float lse = mx + __logf(sum);
+    for (int c = 0; c < C; ++c) sum += expf(z[c] - mx);      // full-precision libm forms: this value is logged as `loss`
+    float lse = mx + logf(sum);
     const int64_t t64 = targets[r];
     const bool ok = t64 >= 0 && t64 < C;
     const int t = ok ? (int)t64 : 0;
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(1024) ce_fwd_bwd_kernel(const float* __restric
     float inv = 1.0f / sum;
     float* dz = dlogits + (long)r * C;
     for (int c = 0; c < C; ++c) {
-      float p = __expf(z[c] - mx) * inv;
+      float p = expf(z[c] - mx) * inv;
       dz[c] = ok ? (p - (c == t ? 1.f : 0.f)) * invB : 0.f;
     }
     preds[r] = arg;
@@ -188,6 +188,37 @@ void launch_adam_flat(float* p, float* g, float* m, float* v, const float* aux, 
   hipLaunchKernelGGL(adam_flat_kernel, dim3((int)grid), dim3(256), 0, s, p + start, g + start, m + start,
                      v + start, aux, n4, (float)lr, (float)b1, (float)b2, (float)(1.0 - b1), (float)(1.0 - b2),
                      (float)eps, (float)wd, zero_grad);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fence-test helpers (tests/test_gpu_fences.py; reducer.cpp / p2p.cpp / parallel/dp.py `test_hook`).  On a one-GPU
+// box every RCCL collective of a world of one is an identity, so a missing stream fence cannot change a bit.  With
+// the hook enabled the engines enqueue `spin` + `scale by 0.5` on their communication stream between their two
+// fences: the scale makes the communication stream's work visible in the data, the spin makes a missing fence lose
+// the race deterministically.  The spin is bounded by a wall-clock deadline AND an iteration cap.
+// ---------------------------------------------------------------------------------------------
+__global__ void spin_kernel(long long ticks, int* sink) {
+  const long long t0 = wall_clock64();
+  long long it = 0;
+  while (wall_clock64() - t0 < ticks && it < (1LL << 33)) ++it;
+  if (sink != nullptr && it == -1) sink[0] = 1;      // never true: keeps the loop alive without a store
+}
+
+void launch_spin(double micros, hipStream_t s) {
+  // wall_clock64 ticks at 100 MHz on gfx9 (constant, independent of the shader clock)
+  const long long ticks = (long long)(micros * 100.0);
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, s, ticks, (int*)nullptr);
+}
+
+__global__ void __launch_bounds__(256) scale_kernel(float* __restrict__ p, long n, float a) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) p[i] *= a;
+}
+
+void launch_scale(float* p, long n, float a, hipStream_t s) {
+  if (n <= 0) return;
+  long grid = (n + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)grid), dim3(256), 0, s, p, n, a);
 }
 
 }  // namespace ddl

@@ -12,7 +12,20 @@
 //
 // The Python `DataParallelEngine` (parallel/dp.py) delegates to this class on a GPU; the CPU / gloo
 // test transport keeps the pure-Python path (host-staged tensors, no streams).
+//
+// Two transports: `direct` (an owned communicator, rccl_comm.h) enqueues ncclReduceScatter / ncclAllGather /
+// ncclAllReduce on the communication stream ITSELF - the two fences then order the RCCL kernels directly; without
+// it the collectives go through the c10d process group (whose internal stream is fenced against the communication
+// stream on both sides: two more event hops and a Work object per bucket).
+//
+// Fence tests (tests/test_gpu_fences.py): on a one-GPU box every collective of a world of one is an identity, so a
+// missing fence cannot change a bit.  `test_hook` = 1 enqueues spin(`hook_spin_us`) + "segment *= 0.5" on the stream
+// that carried the collective, between the bucket-ready and the grads-ready fence; `skip_fence` deliberately leaves
+// one of the two fences out (1 = bucket-ready, 2 = grads-ready) - the negative control those tests must FAIL on.
+// Both are constructor arguments (never environment variables) and default to off.
 #include "torch_hip.h"
+#include "ddl_kernels.h"
+#include "rccl_comm.h"
 
 #include <ATen/hip/HIPEvent.h>
 #include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
@@ -34,12 +47,20 @@ class BucketReducer {
                 std::vector<int64_t> slot_segment, std::vector<int64_t> seg_pending,
                 c10::intrusive_ptr<c10d::ProcessGroup> pg, int64_t rank, int64_t world, bool zero1, bool allreduce,
                 bool serialize, bool timing, int64_t comm_stream_id, int64_t comm_device_index,
-                int64_t comm_device_type)
+                int64_t comm_device_type, std::shared_ptr<ddl::RcclComm> direct, int64_t test_hook,
+                double hook_spin_us, int64_t skip_fence)
       : grad_(std::move(flat_grad)), seg_start_(std::move(seg_start)), seg_end_(std::move(seg_end)),
         slot_segment_(std::move(slot_segment)), pending0_(std::move(seg_pending)), pg_(std::move(pg)),
         rank_(rank), world_(world), zero1_(zero1), allreduce_(allreduce), serialize_(serialize), timing_(timing),
         comm_(c10::Stream::unpack3(comm_stream_id, (c10::DeviceIndex)comm_device_index,
-                                   (c10::DeviceType)comm_device_type)) {   // the engine's communication stream
+                                   (c10::DeviceType)comm_device_type)),    // the engine's communication stream
+        direct_(std::move(direct)), test_hook_(test_hook), hook_spin_us_(hook_spin_us), skip_fence_(skip_fence) {
+    TORCH_CHECK(direct_ != nullptr || pg_, "BucketReducer needs a process group or an owned communicator");
+    if (direct_ != nullptr) {
+      TORCH_CHECK(direct_->nranks() == world && direct_->rank() == rank, "owned communicator: rank / world differ from the group's");
+      TORCH_CHECK(direct_->device() == grad_.device().index(), "owned communicator lives on another device");
+      TORCH_CHECK(grad_.scalar_type() == at::kFloat, "owned communicator path: fp32 gradient arena");
+    }
     TORCH_CHECK(comm_.device_index() == grad_.device().index(), "communication stream lives on another device");
     TORCH_CHECK(grad_.is_cuda() && grad_.dim() == 1 && grad_.is_contiguous(), "flat_grad: contiguous 1-D GPU tensor");
     TORCH_CHECK(seg_start_.size() == seg_end_.size() && seg_start_.size() == pending0_.size(), "segment tables differ");
@@ -79,7 +100,7 @@ class BucketReducer {
     at::Tensor shard = full.narrow(0, rank_ * n, n);
     const Stream main = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(grad_.device().index());
     const Stream where = serialize_ ? main : comm_;       // --debug-sync: everything on the compute stream
-    if (!serialize_) {
+    if (!serialize_ && skip_fence_ != 1) {                // bucket-ready: compute -> communication stream
       Event ready;
       ready.record(main);
       ready.block(comm_);
@@ -91,7 +112,16 @@ class BucketReducer {
         t0 = std::make_unique<Event>(hipEventDefault);
         t0->record(where);
       }
-      if (allreduce_) {
+      if (direct_ != nullptr) {
+        // owned communicator: the RCCL kernels are enqueued on `where` itself (in place: shard == full + rank * n)
+        float* base = grad_.data_ptr<float>() + seg_start_[k];
+        if (allreduce_) {
+          direct_->all_reduce(base, (size_t)(n * world_), ncclFloat32, ncclAvg, where.stream());
+        } else {
+          direct_->reduce_scatter(base, base + rank_ * n, (size_t)n, ncclFloat32, ncclAvg, where.stream());
+          if (!zero1_) direct_->all_gather(base + rank_ * n, base, (size_t)n, ncclFloat32, where.stream());
+        }
+      } else if (allreduce_) {
         c10d::AllreduceOptions opts;
         opts.reduceOp = c10d::ReduceOp::AVG;
         std::vector<at::Tensor> ts{full};
@@ -102,13 +132,17 @@ class BucketReducer {
         pg_->_reduce_scatter_base(shard, full, opts)->wait();     // in place: shard is this rank's slice of full
         if (!zero1_) pg_->_allgather_base(full, shard)->wait();
       }
+      if (test_hook_) {        // visible work of the communication stream between the two fences (fence tests)
+        if (hook_spin_us_ > 0) ddl::launch_spin(hook_spin_us_, where.stream());
+        ddl::launch_scale(full.data_ptr<float>(), full.numel(), 0.5f, where.stream());
+      }
       if (timing_) {
         t1 = std::make_unique<Event>(hipEventDefault);
         t1->record(where);
         spans_.emplace_back(std::move(t0), std::move(t1));
       }
     }
-    if (!serialize_) {
+    if (!serialize_) {                                     // grads-ready: communication -> compute stream (finish)
       done_.emplace_back();
       done_.back().record(comm_);
     }
@@ -121,7 +155,8 @@ class BucketReducer {
       for (size_t k = 0; k < launched_.size(); ++k)
         if (!launched_[k]) segment_ready((int64_t)k);
     const Stream main = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(grad_.device().index());
-    for (auto& ev : done_) ev.block(main);
+    if (skip_fence_ != 2)
+      for (auto& ev : done_) ev.block(main);
     done_.clear();
     reset();
   }
@@ -146,6 +181,7 @@ class BucketReducer {
     allreduce_ = on;
   }
   int64_t launches() const { return launches_; }
+  bool direct() const { return direct_ != nullptr; }
 
  private:
   void reset() {
@@ -160,6 +196,10 @@ class BucketReducer {
   int64_t rank_, world_;
   bool zero1_, allreduce_, serialize_, timing_;
   Stream comm_;
+  std::shared_ptr<ddl::RcclComm> direct_;
+  int64_t test_hook_;
+  double hook_spin_us_;
+  int64_t skip_fence_;
   bool armed_ = true;
   std::vector<Event> done_;
   std::vector<std::pair<std::unique_ptr<Event>, std::unique_ptr<Event>>> spans_;
@@ -172,12 +212,15 @@ void register_reducer(pybind11::module_& m) {
   pybind11::class_<BucketReducer>(m, "BucketReducer")
       .def(pybind11::init<at::Tensor, std::vector<int64_t>, std::vector<int64_t>, std::vector<int64_t>,
                           std::vector<int64_t>, c10::intrusive_ptr<c10d::ProcessGroup>, int64_t, int64_t, bool, bool,
-                          bool, bool, int64_t, int64_t, int64_t>(),
+                          bool, bool, int64_t, int64_t, int64_t, std::shared_ptr<ddl::RcclComm>, int64_t, double,
+                          int64_t>(),
            pybind11::arg("flat_grad"), pybind11::arg("seg_start"), pybind11::arg("seg_end"),
            pybind11::arg("slot_segment"), pybind11::arg("seg_pending"), pybind11::arg("process_group"),
            pybind11::arg("rank"), pybind11::arg("world"), pybind11::arg("zero1"), pybind11::arg("allreduce"),
            pybind11::arg("serialize"), pybind11::arg("timing"), pybind11::arg("comm_stream_id"),
-           pybind11::arg("comm_device_index"), pybind11::arg("comm_device_type"))
+           pybind11::arg("comm_device_index"), pybind11::arg("comm_device_type"),
+           pybind11::arg("direct") = std::shared_ptr<ddl::RcclComm>(), pybind11::arg("test_hook") = 0,
+           pybind11::arg("hook_spin_us") = 0.0, pybind11::arg("skip_fence") = 0)
       .def("arm", &BucketReducer::arm, pybind11::arg("armed"), pybind11::arg("rearm"))
       .def("param_ready", &BucketReducer::param_ready)
       .def("segment_ready", &BucketReducer::segment_ready)
@@ -185,5 +228,6 @@ void register_reducer(pybind11::module_& m) {
       .def("drain_ms", &BucketReducer::drain_ms)
       .def("set_timing", &BucketReducer::set_timing)
       .def("set_allreduce", &BucketReducer::set_allreduce)
-      .def_property_readonly("launches", &BucketReducer::launches);
+      .def_property_readonly("launches", &BucketReducer::launches)
+      .def_property_readonly("direct", &BucketReducer::direct);
 }

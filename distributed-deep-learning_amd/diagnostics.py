@@ -187,7 +187,7 @@ def _check(name: str, got: torch.Tensor, want: torch.Tensor, rank: int) -> None:
 
 
 def first_contact_ladder(ctx: "comm.CommContext", pipeline: bool = False, wd: Optional[StageWatchdog] = None,
-                         stage_seconds: float = 120.0, numel: int = 1 << 16) -> List[str]:
+                         stage_seconds: float = 120.0, numel: int = 1 << 16, rccl: str = "auto") -> List[str]:
     """Run the rungs listed in the module docstring on the WORLD group; returns the names of the completed
     stages.  A world of one runs them only under ``DDL_FORCE_COLLECTIVES=1`` (one-GPU rehearsal; the P2P ring
     then also needs ``DDL_P2P_ALLOW_SELF=1``)."""
@@ -218,8 +218,18 @@ def first_contact_ladder(ctx: "comm.CommContext", pipeline: bool = False, wd: Op
     want = base * float((ranks + 1).mean())
     native = (dev.type == "cuda" and comm.backend_of() == "nccl" and ops.have_ext()
               and os.environ.get("DDL_NATIVE_REDUCER", "1") == "1")
+    direct = None
+    if native and comm.rccl_transport(rccl) == "direct":
+        # the communicator the data-parallel engine of a world-wide group will reuse (same tag, same members)
+        with wd.stage("owned RCCL communicator: unique id through the store, ncclCommInitRank, all-reduce", stage_seconds):
+            direct = comm.direct_comm(list(range(world)), dev, tag="dp")
+            t = torch.full((n,), float(rank + 1), dtype=torch.float32, device=dev)
+            direct.all_reduce(t, False)
+            _sync(dev)
+            direct.check_async()
+            _check("owned RCCL communicator all-reduce", t[:8], torch.full((8,), float((ranks + 1).sum())), rank)
     for form in ("rs_ag", "allreduce"):
-        name = f"bucket reducer ({'csrc/reducer.cpp' if native else 'python'}): " + \
+        name = f"bucket reducer ({('csrc/reducer.cpp, ' + ('owned communicator' if direct is not None else 'c10d')) if native else 'python'}): " + \
                ("in-place reduce-scatter(AVG) + all-gather" if form == "rs_ag" else "all-reduce(AVG)")
         with wd.stage(name, stage_seconds):
             g = base * float(rank + 1)
@@ -230,7 +240,7 @@ def first_contact_ladder(ctx: "comm.CommContext", pipeline: bool = False, wd: Op
                 red = ops.require_ext().BucketReducer(
                     g, [a for a, _ in bounds], [b for _, b in bounds], list(range(len(bounds))), [1] * len(bounds),
                     dist.group.WORLD, rank, world, False, form == "allreduce", False, False,
-                    cs.stream_id, cs.device_index, cs.device_type)
+                    cs.stream_id, cs.device_index, cs.device_type, direct)
                 red.arm(True, True)
                 for k in range(len(bounds)):
                     red.segment_ready(k)
@@ -249,9 +259,10 @@ def first_contact_ladder(ctx: "comm.CommContext", pipeline: bool = False, wd: Op
             _check(name, g, want, rank)
 
     if pipeline and (world > 1 or os.environ.get("DDL_P2P_ALLOW_SELF") == "1"):
-        with wd.stage("grouped send/recv ring (P2P engine)", stage_seconds):
-            chan = P2PChannel(None, dev)
+        with wd.stage("grouped send/recv ring (P2P engine; one owned communicator + stream per neighbour unless --rccl c10d)",
+                      stage_seconds):
             nxt, prv = (rank + 1) % world, (rank - 1) % world
+            chan = P2PChannel(None, dev, neighbours=[nxt, prv], rccl=rccl)
             payload = torch.full((4096,), float(rank + 1), dtype=torch.float32, device=dev)
             inbox = torch.zeros(4096, dtype=torch.float32, device=dev)
             if world == 2 or world == 1:

@@ -20,7 +20,7 @@ ddp_n_pp.py:139 ``DDP(stage_mod, process_group=dp)``):
                                          last micro-batch only (one sync per step per stage)
   =====================================  ==================================================
 
-Per-bucket collective: ``rs_ag`` (default) = in-place reduce-scatter(AVG) + all-gather of the arena range - on a
+Per-bucket collective (``auto``: all-reduce for 2 ranks, rs_ag from 3 on): ``rs_ag`` = in-place reduce-scatter(AVG) + all-gather of the arena range - on a
 fully connected xGMI node both halves run directly over all 7 links of a GPU; ``allreduce`` = one RCCL launch
 per bucket.  Which one wins at a given world size is a measurement, not a belief: the form can be switched
 between two steps (``set_grad_sync``; the collectives live outside the captured graphs) and ``bench.py`` at
@@ -46,13 +46,14 @@ import torch.distributed as dist
 
 from .. import comm, ops
 from ..utils.arena import FlatArena, FlatBuffers, reverse_named_parameters
-from ..utils.streams import new_stream
+from ..utils.streams import new_stream, new_stream_beside
 
 
 class DataParallelEngine:
     def __init__(self, module: torch.nn.Module, group=None, device=None, bucket_mb: float = 8.0,
-                 grad_sync: str = "rs_ag", sync_buffers: str = "forward", zero1: bool = False,
-                 profiler=None, debug_sync: bool = False, register_hooks: bool = True) -> None:
+                 grad_sync: str = "auto", sync_buffers: str = "forward", zero1: bool = False,
+                 profiler=None, debug_sync: bool = False, register_hooks: bool = True, rccl: str = "auto",
+                 test_hook: int = 0, hook_spin_us: float = 0.0, skip_fence: str = "") -> None:
         self.module = module
         self.group = group
         self.world = comm.get_world_size(group) if comm.is_dist() else 1
@@ -62,6 +63,10 @@ class DataParallelEngine:
         self.single = self.world == 1 and not (comm.is_dist() and comm.force_collectives())
         self.device = torch.device(device) if device is not None else next(module.parameters()).device
         # ZeRO-1 needs the scattered form (each rank keeps only its shard of the reduced gradient)
+        if grad_sync == "auto":
+            grad_sync = "allreduce" if self.world <= 2 else "rs_ag"       # config.py: grad_sync
+        if grad_sync not in ("rs_ag", "allreduce"):
+            raise ValueError(f"grad_sync: {grad_sync!r}")
         self.grad_sync = "rs_ag" if zero1 else grad_sync
         self.sync_buffers_policy = sync_buffers
         self.zero1 = zero1
@@ -83,8 +88,13 @@ class DataParallelEngine:
         self.buffers = getattr(module, "flat_buffers", None) or FlatBuffers(module, self.device)
 
         self.on_cuda = self.device.type == "cuda"
-        self.comm_stream = (new_stream(self.device, avoid=[getattr(module, "side_stream", None)])
-                            if self.on_cuda else None)
+        self.comm_stream = None
+        if self.on_cuda:
+            avoid = [getattr(module, "side_stream", None)]
+            # with real peers the communication stream must sit on another hardware queue than the compute stream
+            # (utils/streams.py: streams that share a queue are serialised on the device whatever the events say)
+            self.comm_stream = (new_stream(self.device, avoid=avoid) if self.single else
+                                new_stream_beside(self.device, [torch.cuda.current_stream(self.device)], avoid=avoid))
         self._done_events: List = []
         self._armed = True
         self._pending = [0] * len(self.arena.segments)
@@ -96,9 +106,20 @@ class DataParallelEngine:
         # Native bucket reducer (csrc/reducer.cpp): on a GPU with an RCCL group the bookkeeping + fences +
         # collectives of the gradient path run in C++; gloo (CPU tests, several ranks on one GPU) keeps
         # the Python path below, which is the same algorithm.
+        # Fence tests (tests/test_gpu_fences.py): `test_hook` makes the communication stream's work visible in the
+        # data (spin + "*= 0.5" between the two fences), `skip_fence` leaves ONE fence out - the negative control:
+        # bucket_ready | grads_ready (gradient buckets), buffers_ready | buffers_done (deferred buffer broadcast).
+        if skip_fence not in ("", "bucket_ready", "grads_ready", "buffers_ready", "buffers_done"):
+            raise ValueError(f"skip_fence: {skip_fence!r}")
+        self._test_hook, self._hook_spin_us, self._skip_fence = int(test_hook), float(hook_spin_us), skip_fence
         self._native = None
+        self._direct = None            # owned RCCL communicator of the dp group (csrc/rccl_comm.cpp)
+        self.transport = "none" if self.single else ("c10d" if comm.backend_of(group) == "nccl" else comm.backend_of(group))
         if (self.on_cuda and not self.single and comm.backend_of(group) == "nccl" and ops.have_ext()
                 and os.environ.get("DDL_NATIVE_REDUCER", "1") == "1"):
+            if comm.rccl_transport(rccl) == "direct":
+                self._direct = comm.direct_comm(comm.group_ranks(group), self.device, tag="dp")
+                self.transport = "direct"
             segs = self.arena.segments
             pending = [sum(1 for i in seg.slots if self.arena.params[i].requires_grad) for seg in segs]
             cs = self.comm_stream
@@ -106,13 +127,14 @@ class DataParallelEngine:
                 self.arena.flat_grad, [s.start for s in segs], [s.end for s in segs], list(self._slot_segment),
                 pending, group if group is not None else dist.group.WORLD, self.rank, self.world, bool(zero1),
                 self.grad_sync == "allreduce", bool(debug_sync), bool(profiler is not None and profiler.enabled),
-                cs.stream_id, cs.device_index, cs.device_type)
+                cs.stream_id, cs.device_index, cs.device_type, self._direct, self._test_hook, self._hook_spin_us,
+                {"bucket_ready": 1, "grads_ready": 2}.get(skip_fence, 0))
             if profiler is not None:
                 profiler.add_source("rccl", self._native.drain_ms, self._native.set_timing)
 
-        # per-forward buffer broadcast behind the forward instead of in front of it (after_forward)
-        self._defer_buffers = (self.on_cuda and not self.single and not debug_sync
-                               and comm.backend_of(group) == "nccl")
+        # per-forward buffer broadcast behind the forward instead of in front of it (after_forward); --debug-sync
+        # keeps the same position in the step and only moves it onto the compute stream (the serial oracle)
+        self._defer_buffers = (self.on_cuda and not self.single and comm.backend_of(group) == "nccl")
         self.broadcast_state()
         if register_hooks:
             for i, p in enumerate(self.arena.params):
@@ -141,12 +163,22 @@ class DataParallelEngine:
         self.broadcast_buffers(include_int=True)
 
     def broadcast_buffers(self, include_int: bool = False) -> None:
+        """Rank 0's BN buffers win.  Runs on the CURRENT stream: through the owned communicator the RCCL kernel is
+        enqueued right there, through c10d it runs on the group's internal stream fenced against the current one."""
         if self.single:
             return
-        if self.buffers.flat_float.numel():
-            comm.broadcast(self.buffers.flat_float, self.src_global, self.group)
-        if include_int and self.buffers.flat_int.numel():
-            comm.broadcast(self.buffers.flat_int, self.src_global, self.group)
+        for flat in (self.buffers.flat_float, self.buffers.flat_int if include_int else None):
+            if flat is None or not flat.numel():
+                continue
+            if self._direct is not None:
+                self._direct.broadcast(flat, 0)                      # root = group rank 0
+            else:
+                comm.broadcast(flat, self.src_global, self.group)
+        if self._test_hook and self.on_cuda and self.buffers.flat_float.numel():
+            ext = ops.require_ext()
+            if self._hook_spin_us > 0:
+                ext.test_spin(self._hook_spin_us, self.device.index or 0)
+            ext.test_scale(self.buffers.flat_float, 0.5)
 
     def pre_forward(self, training: bool = False) -> None:
         """Call before a forward pass (train or eval): DDP's ``broadcast_buffers=True``.
@@ -163,18 +195,23 @@ class DataParallelEngine:
         blocking broadcast in front of every step."""
         if self.sync_buffers_policy != "forward" or not self._defer_buffers:
             return
+        if self.debug_sync:
+            self._timed(self.broadcast_buffers)          # same place in the step, on the compute stream
+            return
         main = torch.cuda.current_stream(self.device)
         ready = torch.cuda.Event()
         ready.record(main)
         with torch.cuda.stream(self.comm_stream):
-            self.comm_stream.wait_event(ready)
+            if self._skip_fence != "buffers_ready":
+                self.comm_stream.wait_event(ready)       # buffers-ready: forward (compute) -> communication stream
             tok = self.profiler.begin("rccl", self.comm_stream) if self.profiler else None
             self.broadcast_buffers()
             if tok is not None:
                 self.profiler.end(tok, self.comm_stream)
             done = torch.cuda.Event()
             done.record(self.comm_stream)
-        self._done_events.append(done)
+        if self._skip_fence != "buffers_done":
+            self._done_events.append(done)               # waited for by finish_grad_sync (communication -> compute)
 
     def epoch_boundary(self) -> None:
         if self.sync_buffers_policy == "epoch":

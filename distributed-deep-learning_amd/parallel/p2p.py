@@ -1,10 +1,17 @@
 """P2P channel of the pipeline schedules: posted transfer groups + tickets.
 
 On a GPU with an RCCL group this is a thin face of the native ``P2PEngine`` (csrc/p2p.cpp): transfers are issued
-from a dedicated P2P stream, a send group is fenced behind the compute stream at the point its payload was
+from dedicated P2P streams, a send group is fenced behind the compute stream at the point its payload was
 produced, receives can be posted ahead of the compute that consumes them, and ``wait(ticket)`` makes the compute
 stream (never the host) wait for exactly one group.  Over gloo - CPU plumbing tests, or several ranks sharing one
 GPU - the same interface runs on ``isend`` / ``irecv`` with host staging for GPU tensors.
+
+Transport (``rccl``: auto | direct | c10d).  ``direct`` - the default when the channel knows its ``neighbours`` -
+gives every neighbour its OWN 2-rank RCCL communicator and its OWN HIP stream (csrc/rccl_comm.cpp): the grouped
+``ncclSend`` / ``ncclRecv`` are enqueued on that stream itself, and a receive pre-posted toward the previous stage
+can never sit in front of a send toward the next one (c10d runs every transfer of a process group FIFO on one
+internal stream).  The communicators are created in one global order - pairs sorted by (lower, higher) group rank
+- so no two ranks ever wait for each other in different ``ncclCommInitRank`` calls.
 
 Reference: ``torch.distributed.pipelining`` issues ``batch_isend_irecv`` from the schedule loop on the compute
 stream and waits right away (pp.py:138-150 -> torch schedules.py:505,758-800).
@@ -18,7 +25,7 @@ import torch
 import torch.distributed as dist
 
 from .. import comm, ops
-from ..utils.streams import new_stream
+from ..utils.streams import new_stream, new_stream_beside
 
 Transfer = Tuple[torch.Tensor, int]          # (tensor, GLOBAL rank of the peer)
 
@@ -35,22 +42,45 @@ class _HostRecv:
 
 
 class P2PChannel:
-    def __init__(self, group, device, debug_sync: bool = False, profiler=None) -> None:
+    def __init__(self, group, device, debug_sync: bool = False, profiler=None,
+                 neighbours: Optional[Sequence[int]] = None, rccl: str = "auto", test_hook: int = 0,
+                 hook_spin_us: float = 0.0, skip_fence: int = 0) -> None:
+        """``neighbours``: GLOBAL ranks this channel will ever talk to (a pipeline stage: previous / next stage).
+        ``test_hook`` / ``skip_fence``: fence tests only (csrc/p2p.cpp)."""
         self.group = group
         self.device = torch.device(device)
         self.profiler = profiler
         self.native = None
         self.stream = None
+        self.streams: List = []          # every stream transfers are issued from (lane streams must avoid them)
+        self.transport = "host"
         self.groups = 0
         self._next = 0
         self._pending = {}
         if (self.device.type == "cuda" and comm.is_dist() and comm.backend_of(group) == "nccl" and ops.have_ext()
                 and os.environ.get("DDL_NATIVE_P2P", "1") == "1"):
-            self.stream = new_stream(self.device)
+            # beside the compute stream: a P2P stream that shares its hardware queue would carry the transfers only in
+            # the gaps between compute kernels (utils/streams.py)
+            self.stream = new_stream_beside(self.device, [torch.cuda.current_stream(self.device)])
+            self.streams = [self.stream]
             s = self.stream
+            links = []
+            me = comm.get_rank(group)
+            if neighbours and comm.rccl_transport(rccl) == "direct":
+                pairs = sorted({tuple(sorted((self._local(int(g)), me))) for g in neighbours if g is not None})
+                for a, b in pairs:                           # one global creation order: (lower, higher) group rank
+                    peer = b if a == me else a
+                    members = sorted({a, b})
+                    globals_ = [dist.get_global_rank(group, r) if group is not None else r for r in members]
+                    c = comm.direct_comm(globals_, self.device, tag="pp-link")
+                    st = new_stream_beside(self.device, [torch.cuda.current_stream(self.device)], avoid=self.streams)
+                    self.streams.append(st)
+                    links.append((peer, c, members.index(peer), st.stream_id, st.device_index, st.device_type))
+            self.transport = "direct" if links else "c10d"
             self.native = ops.require_ext().P2PEngine(
                 group if group is not None else dist.group.WORLD, s.stream_id, s.device_index, s.device_type,
-                bool(debug_sync), bool(profiler is not None and profiler.enabled))
+                bool(debug_sync), bool(profiler is not None and profiler.enabled), links, me,
+                comm.get_world_size(group), int(test_hook), float(hook_spin_us), int(skip_fence))
             if profiler is not None:
                 profiler.add_source("p2p", self.native.drain_ms, self.native.set_timing)
 

@@ -134,7 +134,7 @@ class PipelineStage:
                  recv_shape_fn: Optional[Callable[[int], Tuple[int, ...]]] = None,
                  dtype: torch.dtype = torch.float32, dp_engine=None, hip_graph: bool = False,
                  graph_warmup: int = 2, debug_sync: bool = False, profiler=None, n_lanes: int = 1,
-                 n_fwd_lanes: int = 1) -> None:
+                 n_fwd_lanes: int = 1, rccl: str = "auto") -> None:
         self.module = module
         self.stage_index = stage_index
         self.num_stages = num_stages
@@ -148,7 +148,8 @@ class PipelineStage:
         self.recv_shape_fn = recv_shape_fn
         self.dtype = dtype
         self.dp_engine = dp_engine
-        self.chan = P2PChannel(group, self.device, debug_sync=debug_sync, profiler=profiler)
+        self.chan = P2PChannel(group, self.device, debug_sync=debug_sync, profiler=profiler,
+                               neighbours=[r for r in (self.prev_rank, self.next_rank) if r is not None], rccl=rccl)
         self._act_slots = {}      # (mb_index, shape) -> recv buffer for forward activations
         self._grad_slots = {}     # (mb_index, shape) -> recv buffer for backward gradients
         # hipGraph capture of the per-micro-batch forward / backward (see ``_GraphSet``)
@@ -259,7 +260,7 @@ class PipelineStage:
             # streams on DISTINCT hardware queues (measured, utils/streams.py): two lanes that share a queue are
             # serialised on the device whatever the events say
             avoid = [main, getattr(self.module, "side_stream", None),
-                     getattr(self.dp_engine, "comm_stream", None), self.chan.stream]
+                     getattr(self.dp_engine, "comm_stream", None), *self.chan.streams]
             lanes = concurrent_streams(self.device, self.n_fwd + self.n_lanes, avoid=avoid)
             self.fwd_streams, self.bwd_streams = lanes[:self.n_fwd], lanes[self.n_fwd:]
         begin = torch.cuda.Event()

@@ -147,7 +147,7 @@ class DDPStrategy(Strategy):
                                   pretrained=cfg.pretrained, **self._native_kw(cfg, comm.get_world_size(group)))
         self.dp = DataParallelEngine(self.model, group=group, device=self.device, bucket_mb=cfg.bucket_mb,
                                      grad_sync=cfg.grad_sync, sync_buffers=cfg.sync_buffers,
-                                     zero1=cfg.zero1, profiler=self.profiler, debug_sync=cfg.debug_sync)
+                                     zero1=cfg.zero1, profiler=self.profiler, debug_sync=cfg.debug_sync, rccl=cfg.rccl)
         self.arena = self.dp.arena
         shard = (self.dp.rank, self.dp.world) if (cfg.zero1 and self.dp.world > 1) else None
         self.optimizer = self._make_optimizer(self.arena, shard)
@@ -234,7 +234,7 @@ class PPStrategy(Strategy):
             self.dp = DataParallelEngine(self.model, group=mesh.get_group("dp"), device=self.device,
                                          bucket_mb=cfg.bucket_mb, grad_sync=cfg.grad_sync,
                                          sync_buffers=cfg.sync_buffers, zero1=cfg.zero1,
-                                         profiler=self.profiler, debug_sync=cfg.debug_sync)
+                                         profiler=self.profiler, debug_sync=cfg.debug_sync, rccl=cfg.rccl)
             self.arena = self.dp.arena
             self.dp_rank, self.dp_size = self.dp.rank, self.dp.world
         else:
@@ -267,7 +267,7 @@ class PPStrategy(Strategy):
                                    recv_shape_fn=recv_shape, dp_engine=self.dp,
                                    hip_graph=cfg.hip_graph and native and self.device.type == "cuda",
                                    debug_sync=cfg.debug_sync, profiler=self.profiler, n_lanes=cfg.pp_lanes,
-                                   n_fwd_lanes=cfg.pp_fwd_lanes)
+                                   n_fwd_lanes=cfg.pp_fwd_lanes, rccl=cfg.rccl)
         sched = SCHEDULES[cfg.schedule]
         # two schedules over one stage, like the reference (pp.py:138-150): training (with loss)
         # and loss-less inference for evaluation under no_grad
@@ -281,7 +281,14 @@ class PPStrategy(Strategy):
         tok = prof.begin("step")
         self.optimizer.zero_grad()
         if self.dp is not None:
-            self.dp.pre_forward()
+            # BN-buffer broadcast.  Deviation from the reference, documented (README "Deviations"): torch's
+            # DDP forward inside each stage broadcasts the buffers on EVERY micro-batch forward (torch stage.py:560-568
+            # under ddp_n_pp.py:139); here rank 0's buffers win ONCE per step.  Same fixed point (every replica starts
+            # every step from rank 0's running statistics); what differs is that replicas r > 0 use their own
+            # running statistics for micro-batches 1..M-1 of a step - values that only evaluation reads.
+            # On RCCL the broadcast is deferred behind the step's last forward and rides the communication stream
+            # (`after_forward`, below) instead of blocking the compute stream in front of every pipeline step.
+            self.dp.pre_forward(training=True)
             self.dp.arm(False)
         out, loss = None, None
         if self.is_first and not self.is_last:
@@ -294,6 +301,7 @@ class PPStrategy(Strategy):
         else:
             self.schedule.step(batch_size=batch_size)                          # pp.py:190-191
         if self.dp is not None:
+            self.dp.after_forward()          # the step's forwards are done (lanes joined): buffers travel beside the reduce
             tok2 = prof.begin("exposed_comm")
             self.dp.finish_grad_sync()
             prof.end(tok2)

@@ -83,6 +83,21 @@ def run_concurrently(a: "torch.cuda.Stream", b: "torch.cuda.Stream") -> bool:
     return pair < 0.75 * serial
 
 
+def new_stream_beside(device, beside: Iterable, avoid: Iterable = (), tries: int = 8) -> "torch.cuda.Stream":
+    """A stream whose kernels overlap with those of every stream in ``beside`` (a communication / P2P stream must
+    not share a hardware queue with the compute stream, or its RCCL kernels queue up behind the compute kernels
+    whatever the events say).  Falls back to the last candidate when none of ``tries`` qualifies."""
+    beside = [b for b in beside if b is not None]
+    taken = [s for s in avoid if s is not None] + beside
+    cand = None
+    for _ in range(max(1, tries)):
+        cand = new_stream(device, avoid=taken)
+        if all(run_concurrently(cand, b) for b in beside):
+            return cand
+        taken.append(cand)
+    return cand
+
+
 def concurrent_streams(device, n: int, avoid: Iterable = ()) -> "list[torch.cuda.Stream]":
     """``n`` streams that pairwise run side by side on the device, drawn from torch's pool (up to 24 candidates are
     probed).  Falls back to plain distinct streams for the ones that cannot be found (fewer free hardware queues
