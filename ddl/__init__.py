@@ -15,3 +15,6 @@ __path__ = [_REAL]
 with open(_os.path.join(_REAL, "__init__.py")) as _f:
     exec(compile(_f.read(), _os.path.join(_REAL, "__init__.py"), "exec"))
 del _f
+# one module identity for the directory: importing the hyphenated name through importlib yields THIS module
+import sys as _sys
+_sys.modules.setdefault("distributed-deep-learning_amd", _sys.modules[__name__])

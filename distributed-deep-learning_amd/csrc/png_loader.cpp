@@ -81,8 +81,8 @@ void decode_png(const std::string& path, uint8_t* out, int H, int W) {
   const std::vector<uint8_t> d = read_file(path);
   const PngHeader hd = parse_header(d, path);
   if ((int)hd.h != H || (int)hd.w != W)
-    throw PngError(path + ": image is " + std::to_string(hd.w) + "x" + std::to_string(hd.h) + ", loader expects " +
-                   std::to_string(W) + "x" + std::to_string(H), false);
+    throw std::runtime_error(path + ": image is " + std::to_string(hd.w) + "x" + std::to_string(hd.h) + ", loader expects " +
+                             std::to_string(W) + "x" + std::to_string(H));      // a configuration error, not a decode failure
   int ch;
   switch (hd.color) {
     case 0: ch = 1; break;
@@ -95,7 +95,7 @@ void decode_png(const std::string& path, uint8_t* out, int H, int W) {
   if (hd.depth != 8 || hd.interlace != 0)
     throw PngError(path + ": only 8-bit non-interlaced PNGs are decoded natively", true);
 
-  // walk the chunks: palette + concatenated IDAT stream (CRC of every chunk verified)
+  // walk the chunks: palette + concatenated IDAT stream
   std::vector<uint8_t> pal;
   std::vector<uint8_t> z;
   size_t pos = 8;
@@ -106,7 +106,11 @@ void decode_png(const std::string& path, uint8_t* out, int H, int W) {
     if ((size_t)len > d.size() - pos - 12) throw PngError(path + ": truncated chunk", false);
     const uint8_t* type = d.data() + pos + 4;
     const uint8_t* body = type + 4;
-    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), type, len + 4) != be32(body + len)) throw PngError(path + ": chunk CRC mismatch", false);
+    // CRC of the CRITICAL chunks only (IHDR / PLTE / IDAT / IEND: upper-case first letter) - libpng / PIL, which the
+    // reference's read_image sits on, tolerate a damaged ancillary chunk (tEXt, pHYs, ...) and so does this decoder
+    const bool critical = (type[0] & 0x20) == 0;
+    if (critical && (uint32_t)crc32(crc32(0L, Z_NULL, 0), type, len + 4) != be32(body + len))
+      throw PngError(path + ": CRC mismatch in a critical chunk", false);
     if (std::memcmp(type, "IDAT", 4) == 0) z.insert(z.end(), body, body + len);
     else if (std::memcmp(type, "PLTE", 4) == 0) pal.assign(body, body + len);
     else if (std::memcmp(type, "IEND", 4) == 0) end = true;
@@ -307,9 +311,12 @@ class PngLoader {
       try {
         decode_png(paths_[(size_t)t.file], dst, H_, W_);
       } catch (const PngError& e) {
+        // EVERY decode failure of a slot goes to the per-slot Python fallback (PIL, ddl/data.py) - a file the
+        // reference's torchvision.io.read_image (libpng) accepts must never abort a batch here just because this
+        // decoder is stricter; the fallback raises if PIL cannot read the file either.  I/O errors and a wrong image
+        // size (std::runtime_error below) stay fatal.
         std::lock_guard<std::mutex> lk(b.mu);
-        if (e.unsupported) b.unsupported.push_back(t.slot);
-        else if (b.error.empty()) b.error = e.what();
+        b.unsupported.push_back(t.slot);
       } catch (const std::exception& e) {
         std::lock_guard<std::mutex> lk(b.mu);
         if (b.error.empty()) b.error = e.what();

@@ -235,7 +235,14 @@ class NativePngLoader:
         while self._loader.batches_left():
             x, idx, unsupported = self._loader.next()
             for slot in unsupported:
-                x[slot].copy_(read_png(self.paths[int(idx[slot])]))
+                # whatever the native decoder does not cover or refuses (16-bit, Adam7, a file libpng would still
+                # accept): PIL, like the reference's torchvision.io.read_image; only a file neither can read is fatal
+                path = self.paths[int(idx[slot])]
+                try:
+                    x[slot].copy_(read_png(path))
+                except Exception as e:      # noqa: BLE001
+                    raise RuntimeError(f"{path}: neither the native PNG decoder nor PIL can read this file "
+                                       f"({type(e).__name__}: {e})") from e
             yield x, self.labels[idx]
 
 

@@ -5,7 +5,7 @@ lr=1e-3, betas=(0.9,0.999), eps=1e-8, weight_decay=0, no amsgrad); torch dispatc
 that to a ``foreach`` implementation over 364 tensors.  Here params,
 grads, exp_avg and exp_avg_sq are four contiguous buffers with one layout
 (``ddl.utils.arena.FlatArena``) and the step is a single elementwise kernel
-(``ddl.ops.adam_step_flat`` -> csrc/adam.hip) that can also clear the gradients,
+(``ddl.ops.adam_step_flat`` -> ``adam_flat_kernel`` in csrc/elementwise.hip) that can also clear the gradients,
 replacing ``zero_grad`` (K13).  The step counter lives on the device so the whole
 train step can be captured into a hipGraph.
 

@@ -230,5 +230,26 @@ def test_native_png_loader_falls_back_per_file(tmp_path):
     assert torch.equal(batches[0][0][2], data.read_png(ds.root_dir / f"{ds.names[2]}.png"))
     broken = ds.root_dir / f"{ds.names[1]}.png"
     broken.write_bytes(broken.read_bytes()[:60])
-    with pytest.raises(RuntimeError, match="truncated"):
+    with pytest.raises(RuntimeError, match="neither the native PNG decoder nor PIL"):
         list(data.NativePngLoader(ds, 4, range(len(ds)), num_workers=2, drop_last=False))
+
+
+def test_native_png_decoder_is_no_stricter_than_libpng(tmp_path):
+    """a damaged ANCILLARY chunk (tEXt with a wrong CRC) must not abort a batch - libpng / PIL, which the
+    reference's read_image sits on, ignore it; the native decoder checks the CRC of critical chunks only, and any
+    decode failure of a slot goes to the per-slot PIL fallback instead of failing the epoch."""
+    import struct
+    import zlib
+    root = data.make_png_dataset(tmp_path, 4, 2, image_size=16)
+    ds = data.AptosDataset(root / "train.csv", root / "train_images", "new_id_code", "diagnosis")
+    victim = ds.root_dir / f"{ds.names[1]}.png"
+    want = data.read_png(victim)
+    blob = victim.read_bytes()
+    body = b"Comment\x00damaged ancillary chunk"
+    bad = struct.pack(">I", len(body)) + b"tEXt" + body + struct.pack(">I", (zlib.crc32(b"tEXt" + body) ^ 0xFFFF) & 0xFFFFFFFF)
+    victim.write_bytes(blob[:33] + bad + blob[33:])                 # right behind IHDR (8 + 25 bytes)
+    from ddl import ops
+    if ops.have_ext():
+        assert torch.equal(ops.require_ext().decode_png(str(victim)), want)       # decoded natively, CRC of tEXt ignored
+    batches = list(data.NativePngLoader(ds, 4, range(len(ds)), num_workers=2, drop_last=False))
+    assert torch.equal(batches[0][0][1], want)
