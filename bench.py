@@ -72,7 +72,8 @@ def main() -> None:
     ap.add_argument("--batch-per-gpu", type=int, default=None, help="per-replica batch (default: 30, or the preset's)")
     ap.add_argument("--mode", default="ddp", choices=["ddp", "pp", "ddpnpp"])
     ap.add_argument("--preset", default="parity", choices=sorted(PRESETS))
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "fp32x3"],
+                    help="fp32 = the reference's precision on the fp32 MFMA (headline); bf16 / fp32x3 = optional modes")
     ap.add_argument("--schedule", default="1f1b")
     ap.add_argument("--microbatches", type=int, default=None)
     ap.add_argument("--pp-size", type=int, default=2)

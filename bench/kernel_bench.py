@@ -16,6 +16,8 @@ ap.add_argument("--only", default=None)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--bm", type=int, default=0)
 ap.add_argument("--bf16", action="store_true", help="bf16 MFMA inputs for the conv_gemm cases")
+ap.add_argument("--prec", type=int, default=None, help="matrix-core path of the conv_gemm cases: 0 fp32 MFMA, 1 bf16, 3 fp32 as "
+                                                     "three bf16 pieces (6 bf16 MFMAs per product)")
 ap.add_argument("--min-rows", type=int, default=64, help="wgrad: minimum pixel rows per workgroup")
 ap.add_argument("--sub", type=int, default=0, help="wgrad 1x1: force the sub-tile count (1, 3, 4) of the channel tiles")
 ap.add_argument("--defer", action="store_true", help="wgrad: queue the slab reductions (timed: the slab kernels alone)")
@@ -26,6 +28,7 @@ ap.add_argument("--cfg", type=int, default=-1, help="explicit conv_gemm tile con
 a = ap.parse_args()
 if a.cfg >= 0:
     a.bm = 1000 + a.cfg
+a.bf16 = int(a.bf16) if a.prec is None else a.prec
 ext = ops.require_ext()
 dev = torch.device("cuda", 0)
 B = a.batch
@@ -179,7 +182,10 @@ for name, flops, fn in cases:
         res = []
         for cfg in [-1] + list(range(NCFG)):
             a.bm = 0 if cfg < 0 else 1000 + cfg
-            res.append(timeit(fn, 10))
+            try:
+                res.append(timeit(fn, 10))
+            except RuntimeError:          # a tile configuration without an fp32x3 form (LDS)
+                res.append(float("inf"))
         best = min(range(1, NCFG + 1), key=lambda i: res[i])
         print(f"{name:20s} auto {res[0]:6.1f} | " + " ".join(f"{r:6.1f}" for r in res[1:]) +
               f" | best cfg {best - 1} {res[best]:6.1f} us", flush=True)

@@ -103,7 +103,7 @@ ddl::FusedK make_fk(const OptT& acc, const OptT& mean, const OptT& rstd, const O
 at::Tensor conv_gemm(const at::Tensor& x0, const OptT& x1, const OptT& s0, const OptT& s1, const OptT& s2,
                      bool relu, int64_t M, int64_t H, int64_t W, int64_t taps, bool flip,
                      const at::Tensor& weight, bool b_kmajor, at::Tensor out, bool ep_mask, bool ep_accum,
-                     const OptT& aux, const OptT& e0, const OptT& e1, int64_t stats_mode, int64_t force_bm, bool bf16,
+                     const OptT& aux, const OptT& e0, const OptT& e1, int64_t stats_mode, int64_t force_bm, int64_t prec,
                      const OptT& acc_out, const OptT& k_acc, const OptT& k_mean, const OptT& k_rstd,
                      const OptT& k_scale, const OptT& k_dgamma, const OptT& k_dbeta, double k_count,
                      const OptT& tail_counters, int64_t tail_mode, double tail_count, const OptT& tail_mean,
@@ -140,7 +140,8 @@ at::Tensor conv_gemm(const at::Tensor& x0, const OptT& x1, const OptT& s0, const
   TORCH_CHECK(stats_mode >= 0 && stats_mode <= 2, "stats_mode");
   if (stats_mode == 2) { TORCH_CHECK(p.aux, "stats_mode 2 needs aux"); }
   p.stats = (int)stats_mode;
-  p.bf16 = bf16 ? 1 : 0;
+  TORCH_CHECK(prec == 0 || prec == 1 || prec == 3, "prec: 0 (fp32 MFMA), 1 (bf16), 3 (fp32 as three bf16 pieces)");
+  p.bf16 = (int)prec;
   // operation kind: the combinations DenseNet uses (conv_gemm.hip)
   const bool two = x1.has_value();
   if (!two && !b_kmajor && !ep_mask && !ep_accum && stats_mode != 2) p.kind = 0;
@@ -205,7 +206,7 @@ void conv_fwd_fused(const at::Tensor& x, const at::Tensor& acc_in, int64_t new0,
                     const at::Tensor& beta, const OptT& run_mean, const OptT& run_var, at::Tensor scale_out,
                     at::Tensor shift_out, at::Tensor mean, at::Tensor var, at::Tensor rstd, double count,
                     double momentum, double eps, int64_t M, int64_t H, int64_t W, int64_t taps,
-                    const at::Tensor& weight, at::Tensor out, at::Tensor acc_out, int64_t force_bm, bool bf16) {
+                    const at::Tensor& weight, at::Tensor out, at::Tensor acc_out, int64_t force_bm, int64_t prec) {
   ddl::DeviceGuard guard(x.device());
   const int64_t C = x.size(1), N = out.size(1);
   TORCH_CHECK(taps == 1 || taps == 9, "taps must be 1 or 9");
@@ -252,7 +253,8 @@ void conv_fwd_fused(const at::Tensor& x, const at::Tensor& acc_in, int64_t new0,
   p.bn.eps = (float)eps;
   p.stats = 3;
   p.kind = 0;
-  p.bf16 = bf16 ? 1 : 0;
+  TORCH_CHECK(prec == 0 || prec == 1 || prec == 3, "prec: 0 (fp32 MFMA), 1 (bf16), 3 (fp32 as three bf16 pieces)");
+  p.bf16 = (int)prec;
   const int64_t cch = C / 32;
   TORCH_CHECK(taps * cch <= 320, "conv_fwd_fused: K too large for the sub-slab index arithmetic");
   p.inv_cc = (int)((65536 + cch - 1) / cch);
@@ -534,7 +536,7 @@ void register_conv_ops(pybind11::module_& m) {
         pybind11::arg("relu"), pybind11::arg("M"), pybind11::arg("H"), pybind11::arg("W"), pybind11::arg("taps"),
         pybind11::arg("flip"), pybind11::arg("weight"), pybind11::arg("b_kmajor"), pybind11::arg("out"),
         pybind11::arg("ep_mask"), pybind11::arg("ep_accum"), pybind11::arg("aux"), pybind11::arg("e0"),
-        pybind11::arg("e1"), pybind11::arg("stats_mode"), pybind11::arg("force_bm"), pybind11::arg("bf16") = false,
+        pybind11::arg("e1"), pybind11::arg("stats_mode"), pybind11::arg("force_bm"), pybind11::arg("prec") = 0,
         pybind11::arg("acc_out") = c10::nullopt, pybind11::arg("k_acc") = c10::nullopt,
         pybind11::arg("k_mean") = c10::nullopt, pybind11::arg("k_rstd") = c10::nullopt,
         pybind11::arg("k_scale") = c10::nullopt, pybind11::arg("k_dgamma") = c10::nullopt,

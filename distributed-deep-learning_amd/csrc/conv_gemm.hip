@@ -50,13 +50,32 @@ namespace {
 //   2 DGRAD3  two sources, k-major, masked store                  (+ statistics g, g*aux)
 //   3 DGRAD1  two sources, k-major, masked accumulate into out    (+ statistics g, g*aux)
 //
-// BF = true: bf16 matrix-core inputs, fp32 accumulate (`--dtype bf16`).  Storage stays fp32; the
+// PREC = 1: bf16 matrix-core inputs, fp32 accumulate (`--dtype bf16`).  Storage stays fp32; the
 // operands are rounded (RNE, v_cvt_pk_bf16_f32) when they are written to LDS, after the fused
 // BN/ReLU prologue, and consumed by v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).  Both LDS
 // images are then K-contiguous bf16 rows of 2*BKT + 16 bytes (conflict-free ds_read_b128); k-major
 // weights are transposed while being staged, so the MFMA loop is the same for every kind.
-template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF, int KIND, bool BF, bool RB>
+//
+// PREC = 3: fp32 arithmetic ON the bf16 matrix cores (`--dtype fp32x3`).  gfx950 runs fp32 MFMA at 1/16 of the
+// bf16 rate and has no TF32, so an fp32 operand is split into three bf16 pieces when it is written to LDS
+// (x = hi + mid + lo exactly to 2^-25 |x|: each residual x - bf16(x) is exact in fp32) and a product is the sum of
+// the six piece products of weight >= 2^-16 (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid - every bf16 x bf16
+// product is exact in the fp32 accumulator); the three dropped ones are <= 2^-23 |a*b| together, the size of the
+// rounding of ONE fp32 multiply-add.  6 bf16 MFMAs replace 16 fp32 MFMAs of the same cycles each: 2.7x the fp32
+// matrix-core roof at fp32-level accuracy (tests/test_gpu_split.py compares both paths with fp64).
+// x -> (hi, mid, lo) bf16, RNE at every level (the residuals are exact)
+__device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+  h = __builtin_convertvector(v, bf16x4);
+  f32x4 r = v - __builtin_convertvector(h, f32x4);
+  m = __builtin_convertvector(r, bf16x4);
+  r = r - __builtin_convertvector(m, f32x4);
+  l = __builtin_convertvector(r, bf16x4);
+}
+
+template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF, int KIND, int PREC, bool RB>
 __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const ConvGemmParams p) {
+  constexpr bool BF = PREC != 0;         // operands live in LDS as bf16 images
+  constexpr int NP = PREC == 3 ? 3 : 1;  // images per operand (split pieces)
   constexpr bool TWO = KIND >= 2, KMAJOR = KIND >= 1;
   constexpr int LDH = 32 * KS + 8;       // bf16 image row stride (elements)
   constexpr int NT = 64 * WM * WN * KS;
@@ -88,8 +107,8 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
   float* k1s = smem + 2 * p.C;
   float* As = smem + soff;                 // [NBUF][BM][LDA]
   float* Bs = As + NBUF * BM * LDA;        // [NBUF][B_ELEMS]
-  __bf16* Ah = reinterpret_cast<__bf16*>(smem + soff);   // BF: [NBUF][BM][LDH]
-  __bf16* Bh = Ah + NBUF * BM * LDH;                     //     [NBUF][BN][LDH]
+  __bf16* Ah = reinterpret_cast<__bf16*>(smem + soff);   // BF: [NBUF][NP][BM][LDH]
+  __bf16* Bh = Ah + NBUF * NP * BM * LDH;                //     [NBUF][NP][BN][LDH]
 
   // wave index as a scalar: the wave-uniform sub-tile guards then branch on SCC instead of masking EXEC
   // (the BN = 32 forms have no live guard; scalarising them only moves an index table to scratch)
@@ -221,8 +240,8 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
   auto store_slab = [&](int buf, const Stage& S) {
     float* Ab = As + buf * BM * LDA;
     float* Bb = Bs + buf * B_ELEMS;
-    __bf16* Ahb = Ah + buf * BM * LDH;
-    __bf16* Bhb = Bh + buf * BN * LDH;
+    __bf16* Ahb = Ah + buf * NP * BM * LDH;
+    __bf16* Bhb = Bh + buf * NP * BN * LDH;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       f32x4 v = S.a_v0[i];
@@ -235,18 +254,34 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
         }
         if (!((S.a_mask >> i) & 1u)) v = zero4;
       }
-      if (BF) *reinterpret_cast<bf16x4*>(Ahb + (a_row0 + i * RSTEP) * LDH + 4 * aq) = __builtin_convertvector(v, bf16x4);
-      else *reinterpret_cast<f32x4*>(Ab + (a_row0 + i * RSTEP) * LDA + 4 * aq) = v;
+      if (PREC == 3) {
+        bf16x4 h0, h1, h2;
+        split3(v, h0, h1, h2);
+        __bf16* q = Ahb + (a_row0 + i * RSTEP) * LDH + 4 * aq;
+        *reinterpret_cast<bf16x4*>(q) = h0;
+        *reinterpret_cast<bf16x4*>(q + BM * LDH) = h1;
+        *reinterpret_cast<bf16x4*>(q + 2 * BM * LDH) = h2;
+      } else if (BF) {
+        *reinterpret_cast<bf16x4*>(Ahb + (a_row0 + i * RSTEP) * LDH + 4 * aq) = __builtin_convertvector(v, bf16x4);
+      } else {
+        *reinterpret_cast<f32x4*>(Ab + (a_row0 + i * RSTEP) * LDA + 4 * aq) = v;
+      }
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       if (BF) {
-        const bf16x4 h = __builtin_convertvector(S.b_reg[i], bf16x4);
-        if (!KMAJOR) {
-          *reinterpret_cast<bf16x4*>(Bhb + (a_row0 + i * RSTEP) * LDH + 4 * aq) = h;
-        } else {             // transpose on the way in: this thread holds 4 output channels of one k
-          __bf16* q = Bhb + 4 * (tid - bk_row * BQ4) * LDH + (bk_row + i * KROWS);
-          q[0] = h[0]; q[LDH] = h[1]; q[2 * LDH] = h[2]; q[3 * LDH] = h[3];
+        bf16x4 hp[3];
+        if (PREC == 3) split3(S.b_reg[i], hp[0], hp[1], hp[2]);
+        else hp[0] = __builtin_convertvector(S.b_reg[i], bf16x4);
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) {
+          const bf16x4 h = hp[pc];
+          if (!KMAJOR) {
+            *reinterpret_cast<bf16x4*>(Bhb + pc * BN * LDH + (a_row0 + i * RSTEP) * LDH + 4 * aq) = h;
+          } else {             // transpose on the way in: this thread holds 4 output channels of one k
+            __bf16* q = Bhb + pc * BN * LDH + 4 * (tid - bk_row * BQ4) * LDH + (bk_row + i * KROWS);
+            q[0] = h[0]; q[LDH] = h[1]; q[2 * LDH] = h[2]; q[3 * LDH] = h[3];
+          }
         }
       } else if (!KMAJOR) {
         *reinterpret_cast<f32x4*>(Bb + (a_row0 + i * RSTEP) * LDA + 4 * aq) = S.b_reg[i];
@@ -265,6 +300,35 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto compute = [&](int buf) {
+    if (PREC == 3) {
+      const __bf16* Ab = Ah + buf * NP * BM * LDH + (wm * TM * 32 + li) * LDH + ks * 32 + 8 * lh;
+      const __bf16* Bb = Bh + buf * NP * BN * LDH + (wn * TN * 32 + li) * LDH + ks * 32 + 8 * lh;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {        // two 16-wide k steps per 32-wide sub-slab, three pieces per operand
+        bf16x8 af[3][TM], bf[3][TN];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[pc][i] = *reinterpret_cast<const bf16x8*>(Ab + pc * BM * LDH + i * 32 * LDH + 16 * s);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bf[pc][j] = *reinterpret_cast<const bf16x8*>(Bb + pc * BN * LDH + j * 32 * LDH + 16 * s);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (n0 + (wn * TN + j) * 32 >= p.N) continue;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {     // small terms first; one accumulation chain per tile runs back to back
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+      return;
+    }
     if (BF) {
       const __bf16* Ab = Ah + buf * BM * LDH + (wm * TM * 32 + li) * LDH + ks * 32 + 8 * lh;
       const __bf16* Bb = Bh + buf * BN * LDH + (wn * TN * 32 + li) * LDH + ks * 32 + 8 * lh;
@@ -404,12 +468,14 @@ __global__ void __launch_bounds__(64 * WM * WN * KS) conv_gemm_kernel(const Conv
   DDL_PROBE(p, 8);
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF, int KIND, bool BF, bool RB>
+template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF, int KIND, int PREC, bool RB>
 void launch_inst_rb(const ConvGemmParams& p, hipStream_t s) {
   constexpr bool KMAJOR = KIND >= 1;
   constexpr int BKT = 32 * KS;
   constexpr size_t b_elems = KMAJOR ? (size_t)BKT * (BN + 4) : (size_t)BN * (BKT + 4);
-  constexpr size_t stage = (NBUF * (size_t)BM * (BKT + 4) + NBUF * b_elems) * sizeof(float);
+  constexpr size_t stage32 = (NBUF * (size_t)BM * (BKT + 4) + NBUF * b_elems) * sizeof(float);
+  constexpr size_t stage3 = (size_t)NBUF * 3 * (BM + BN) * (BKT + 8) * 2;        // three bf16 images per operand
+  constexpr size_t stage = PREC == 3 ? stage3 : stage32;
   // the K-split combine and the statistics reduce reuse the staging area
   constexpr size_t red = (size_t)(KS - 1) * (BM / 32) * (BN / 32) * 16 * 64 * sizeof(float);
   constexpr size_t epi = (size_t)WM * WN * 32 * kEpiLd * sizeof(float);      // epilogue transposition images
@@ -424,38 +490,52 @@ void launch_inst_rb(const ConvGemmParams& p, hipStream_t s) {
   const size_t lds = m1t > m2 ? m1t : m2;
   static bool attr_set = false;
   if (!attr_set) {
-    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, KS, NBUF, PF, KIND, BF, RB>),
+    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, WM, WN, KS, NBUF, PF, KIND, PREC, RB>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     attr_set = true;
   }
   dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.N + BN - 1) / BN));
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, KS, NBUF, PF, KIND, BF, RB>), grid, dim3(64 * WM * WN * KS), lds, s, p);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, KS, NBUF, PF, KIND, PREC, RB>), grid, dim3(64 * WM * WN * KS), lds, s, p);
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF, int KIND, bool BF>
+template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF, int KIND, int PREC>
 void launch_inst(const ConvGemmParams& p, hipStream_t s) {
   // bf16 forms are instantiated rebasing only (not the headline path; halves the kernel count of this file)
-  if (BF || needs_rebase(p.a.bytes0, p.a.bytes1, p.obytes, p.auxbytes)) launch_inst_rb<BM, BN, WM, WN, KS, NBUF, PF, KIND, BF, true>(p, s);
-  else launch_inst_rb<BM, BN, WM, WN, KS, NBUF, PF, KIND, BF, BF>(p, s);       // (BF, RB) = (false, false)
+  if (PREC != 0 || needs_rebase(p.a.bytes0, p.a.bytes1, p.obytes, p.auxbytes)) launch_inst_rb<BM, BN, WM, WN, KS, NBUF, PF, KIND, PREC, true>(p, s);
+  else launch_inst_rb<BM, BN, WM, WN, KS, NBUF, PF, KIND, PREC, PREC != 0>(p, s);       // (PREC, RB) = (0, false)
 }
 
 template <int BM, int BN, int WM, int WN, int KS, int NBUF, int PF = 1>
 void launch_cfg(const ConvGemmParams& p, hipStream_t s) {
   static_assert(PF == 1 || NBUF == 2, "prefetch distance 2 needs both LDS buffers");
+  if (p.bf16 == 3) {
+    // the split form needs 1.5x the staging LDS of fp32: configurations beyond the 160 KB of a CU do not exist
+    if constexpr ((size_t)NBUF * 3 * (BM + BN) * (32 * KS + 8) * 2 + kMaxAffineC * 3 * sizeof(float) <= 160 * 1024) {
+      switch (p.kind) {
+        case 0: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 0, 3>(p, s); break;
+        case 1: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 1, 3>(p, s); break;
+        case 2: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 2, 3>(p, s); break;
+        default: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 3, 3>(p, s); break;
+      }
+      return;
+    } else {
+      throw std::runtime_error("conv_gemm: this tile configuration has no fp32x3 form (LDS)");
+    }
+  }
   if (p.bf16) {
     switch (p.kind) {
-      case 0: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 0, true>(p, s); break;
-      case 1: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 1, true>(p, s); break;
-      case 2: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 2, true>(p, s); break;
-      default: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 3, true>(p, s); break;
+      case 0: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 0, 1>(p, s); break;
+      case 1: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 1, 1>(p, s); break;
+      case 2: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 2, 1>(p, s); break;
+      default: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 3, 1>(p, s); break;
     }
     return;
   }
   switch (p.kind) {
-    case 0: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 0, false>(p, s); break;
-    case 1: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 1, false>(p, s); break;
-    case 2: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 2, false>(p, s); break;
-    default: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 3, false>(p, s); break;
+    case 0: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 0, 0>(p, s); break;
+    case 1: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 1, 0>(p, s); break;
+    case 2: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 2, 0>(p, s); break;
+    default: launch_inst<BM, BN, WM, WN, KS, NBUF, PF, 3, 0>(p, s); break;
   }
 }
 

@@ -607,12 +607,16 @@ class NativeDenseNetStage(nn.Module):
                  dtype: str = "fp32", bucket_mb: float = 8.0, dp_world: int = 1,
                  wgrad_min_rows: int = 64, grad_phases: Sequence[str] = ()) -> None:
         super().__init__()
-        if dtype not in ("fp32", "bf16"):
-            raise ValueError(f"dtype must be fp32 or bf16, got {dtype!r}")
+        if dtype not in ("fp32", "bf16", "fp32x3"):
+            raise ValueError(f"dtype must be fp32, bf16 or fp32x3, got {dtype!r}")
         # bf16: the dense-block / transition forward and data-gradient GEMMs feed the bf16 MFMA (operands
         # rounded at the LDS write, fp32 accumulate); storage, BN statistics, weight gradients, stem, head
         # and Adam stay fp32.  Not the reference's numerics -- never the default, never the headline.
-        self.bf16 = dtype == "bf16"
+        # fp32x3 (experiment, README "dead ends"): fp32 operands split into three bf16 pieces, six bf16 MFMAs per product
+        # in the same GEMMs - fp32-level accuracy (bench/split_accuracy.py), but the staging work triples and the
+        # kernels are staging-bound, so it only wins on the block-1 1x1 forward.
+        # `bf16` is the matrix-core path selector handed to the kernels: 0 fp32 MFMA, 1 bf16, 3 split.
+        self.bf16 = {"fp32": 0, "bf16": 1, "fp32x3": 3}[dtype]
         # Fused BN statistics (csrc/conv_params.h FusedBn / FusedK): forward on by default (2 bn_prep launches
         # per dense layer leave the single-stream forward chain: 10.41 -> 9.92 ms/step at batch 30).  The
         # backward variant (BN2 coefficients derived inside the 1x1 dgrad / wgrad) removes 58 more launches
