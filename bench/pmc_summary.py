@@ -36,3 +36,10 @@ for case, c in cases.items():
     print(f"   MFMA-busy / wave-cycles {c['SQ_VALU_MFMA_BUSY_CYCLES'] / max(c['SQ_WAVE_CYCLES'], 1):.3f}   "
           f"wait-any / wave-cycles {c['SQ_WAIT_ANY'] / max(c['SQ_WAVE_CYCLES'], 1):.3f}   "
           f"LDS bank-conflict cycles / LDS-active cycles {c['SQ_LDS_BANK_CONFLICT'] / max(c['SQ_ACTIVE_INST_LDS'], 1):.4f}")
+    wc = max(c["SQ_WAVE_CYCLES"], 1)
+    if c["SQ_ACTIVE_INST_ANY"]:
+        # disjoint split of a wave's lifetime (MI355X_MICROARCH.md: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES):
+        # parked at s_waitcnt / barrier, stalled at issue (MFMA RAW / pipe busy / LDS issue), issuing
+        print(f"   wave lifetime: parked (s_waitcnt / barrier) {c['SQ_WAIT_ANY'] / wc:.3f} | issue-stalled {c['SQ_WAIT_INST_ANY'] / wc:.3f} | "
+              f"issuing {c['SQ_ACTIVE_INST_ANY'] / wc:.3f}   (issuing: VALU {c['SQ_ACTIVE_INST_VALU'] / wc:.3f}, LDS {c['SQ_ACTIVE_INST_LDS'] / wc:.3f}, "
+              f"MFMA {c['SQ_ACTIVE_INST_MFMA'] / wc:.3f})")

@@ -572,6 +572,10 @@ void launch_by_id(int id, const ConvGemmParams& p, hipStream_t s) {
     case 18: launch_cfg<32, 32, 1, 1, 8, 1>(p, s); break;       // 8 / 16 waves on one 32-row tile: small-M layers
     case 19: launch_cfg<32, 32, 1, 1, 16, 1>(p, s); break;      //   have < 1 workgroup per CU, so the K split supplies
     case 20: launch_cfg<32, 128, 1, 4, 4, 1>(p, s); break;      //   the waves that overlap VALU staging with MFMA
+    // (round 3, measured and removed: 96-row tiles - a grid just under one round of resident workgroups, no tail
+    // round: 94080 rows = 980 tiles at 4 per CU instead of 1470 tiles of 64 at 5 per CU.  profiles/r3/ksweep_b30_96rows.txt:
+    // no better than the 64-row tiles on block 1, 27.0 vs 31.6 us on the block-2 3x3 data gradient - and 8.58 vs 8.56 ms
+    // INSIDE the step, so the configurations are gone again.)
     default: launch_cfg<64, 32, 2, 1, 4, 1>(p, s); break;
   }
 }
