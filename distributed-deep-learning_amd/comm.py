@@ -180,6 +180,30 @@ def direct_comm(ranks, device: torch.device, tag: str = "world", fresh: bool = F
     return c
 
 
+def direct_comm_or_fallback(ranks, device: torch.device, tag: str, group=None, who: str = ""):
+    """``direct_comm`` with a COLLECTIVE verdict: every member reports whether its communicator came up, the group
+    agrees through a c10d MIN all-reduce, and if any member failed EVERY member drops its communicator and returns
+    ``None`` (the caller then stays on the c10d transport).  A rank that silently used another transport than its
+    peers would deadlock the first collective; a first multi-GPU run must degrade loudly instead."""
+    import sys
+    c, err = None, ""
+    try:
+        c = direct_comm(ranks, device, tag)
+    except Exception as e:      # noqa: BLE001 - reported below, the verdict is taken together
+        err = f"{type(e).__name__}: {e}"
+    ok = torch.tensor([1 if c is not None else 0], dtype=torch.int32, device=device)
+    if len(ranks) > 1:
+        dist.all_reduce(ok, dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 1:
+        return c
+    print(f"[rank {get_rank()}] {who or tag}: owned RCCL communicator over ranks {list(ranks)} not available on every "
+          f"member ({err or 'a peer failed'}) - falling back to the c10d transport", file=sys.stderr, flush=True)
+    if c is not None:
+        _DIRECT.pop((tag, tuple(int(r) for r in ranks)), None)
+        c.abort()
+    return None
+
+
 # --------------------------------------------------------------------------------------
 # 2-D mesh
 # --------------------------------------------------------------------------------------

@@ -118,8 +118,9 @@ class DataParallelEngine:
         if (self.on_cuda and not self.single and comm.backend_of(group) == "nccl" and ops.have_ext()
                 and os.environ.get("DDL_NATIVE_REDUCER", "1") == "1"):
             if comm.rccl_transport(rccl) == "direct":
-                self._direct = comm.direct_comm(comm.group_ranks(group), self.device, tag="dp")
-                self.transport = "direct"
+                self._direct = comm.direct_comm_or_fallback(comm.group_ranks(group), self.device, "dp", group,
+                                                            who="DataParallelEngine")
+                self.transport = "direct" if self._direct is not None else "c10d (owned communicator unavailable)"
             segs = self.arena.segments
             pending = [sum(1 for i in seg.slots if self.arena.params[i].requires_grad) for seg in segs]
             cs = self.comm_stream

@@ -68,14 +68,31 @@ class P2PChannel:
             me = comm.get_rank(group)
             if neighbours and comm.rccl_transport(rccl) == "direct":
                 pairs = sorted({tuple(sorted((self._local(int(g)), me))) for g in neighbours if g is not None})
-                for a, b in pairs:                           # one global creation order: (lower, higher) group rank
-                    peer = b if a == me else a
-                    members = sorted({a, b})
-                    globals_ = [dist.get_global_rank(group, r) if group is not None else r for r in members]
-                    c = comm.direct_comm(globals_, self.device, tag="pp-link")
-                    st = new_stream_beside(self.device, [torch.cuda.current_stream(self.device)], avoid=self.streams)
-                    self.streams.append(st)
-                    links.append((peer, c, members.index(peer), st.stream_id, st.device_index, st.device_type))
+                err, made = "", []
+                try:
+                    for a, b in pairs:                       # one global creation order: (lower, higher) group rank
+                        peer = b if a == me else a
+                        members = sorted({a, b})
+                        globals_ = [dist.get_global_rank(group, r) if group is not None else r for r in members]
+                        c = comm.direct_comm(globals_, self.device, tag="pp-link")
+                        made.append(((("pp-link"), tuple(globals_)), c))
+                        st = new_stream_beside(self.device, [torch.cuda.current_stream(self.device)], avoid=self.streams)
+                        self.streams.append(st)
+                        links.append((peer, c, members.index(peer), st.stream_id, st.device_index, st.device_type))
+                except Exception as e:      # noqa: BLE001 - the verdict is taken together, below
+                    err = f"{type(e).__name__}: {e}"
+                # every stage of the pipeline must use the same transport: agree over the pipeline group
+                ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=self.device)
+                if comm.get_world_size(group) > 1:
+                    dist.all_reduce(ok, dist.ReduceOp.MIN, group=group)
+                if int(ok.item()) != 1:
+                    import sys
+                    print(f"[rank {comm.get_rank()}] P2PChannel: per-neighbour RCCL links not available on every stage "
+                          f"({err or 'a peer failed'}) - falling back to the c10d transport", file=sys.stderr, flush=True)
+                    for key, c in made:
+                        comm._DIRECT.pop(key, None)
+                        c.abort()
+                    links, self.streams = [], [self.stream]
             self.transport = "direct" if links else "c10d"
             self.native = ops.require_ext().P2PEngine(
                 group if group is not None else dist.group.WORLD, s.stream_id, s.device_index, s.device_type,

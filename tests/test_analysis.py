@@ -62,3 +62,21 @@ def test_notebook_is_valid_and_uses_the_module():
     src = "\n".join("".join(c["source"]) for c in nb["cells"] if c["cell_type"] == "code")
     assert nb["nbformat"] == 4 and "analysis.epoch_time_by_job" in src and "communication_summary" in src
     compile(src, "main.ipynb", "exec")
+
+
+def test_scaling_model_is_labelled_and_consistent():
+    """ddl/scaling_model.py: the MODELLED multi-GPU table (no multi-GPU machine was available to measure it) - every
+    table says so, a world of one has no communication, more GPUs never reduce the modelled job throughput, and the
+    direct reduce-scatter + all-gather over all links is cheaper than a one-link ring for the same bytes."""
+    from ddl import scaling_model as sm
+    link = sm.Link()
+    assert sm.rs_ag_ms(8e6, 1, link) == 0.0
+    assert sm.rs_ag_ms(8e6, 8, link) < sm.ring_allreduce_ms(8e6, 8, link)
+    r1 = sm.ddp_step_ms(1, 8.56, [8e6], [5.0], 0.05, link)
+    r8 = sm.ddp_step_ms(8, 8.75, [8e6, 8e6, 6e6, 6e6], [3.8, 4.6, 5.4, 8.7], 0.05, link)
+    assert r1["comm_exposed_ms"] == 0.0 and r8["step_ms"] >= 8.75
+    assert 8 * 30 / r8["step_ms"] > 30 / r1["step_ms"]
+    text = sm.tables()
+    assert text.count("MODELLED") >= 3 and "none is a multi-GPU measurement" in text
+    # fill-drain makespan: (M + S - 1) slots
+    assert abs(sm.pipeline_step_ms(2, 5, 1.0, 0.0, sm.Link(lat_us=0.0)) - 6.0) < 1e-9
