@@ -146,7 +146,7 @@ def test_bench_json_contract_cpu(tmp_path):
     assert rec["distinct_devices"] == 1 and rec["ranks_per_device"] == 2 and rec["plumbing_run"] is True
     assert rec["higher_is_better"] is True and rec["scaling"] == "weak" and rec["dtype"] == "fp32"
     assert rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2"
-    assert rec["value"] == pytest.approx(4 * 1 / (rec["ms_per_step"] / 1e3), rel=1e-3)
+    assert rec["value"] == pytest.approx(4 * 1 / (rec["ms_per_step"] / 1e3), rel=5e-3)      # both fields are rounded
     assert "profile" in rec and rec["profile"]["profile_steps"] == 1 and rec["profile"]["step_ms_per_step"] > 0
     # multi-rank runs return the tuning data in the same line: both collective forms and the bucket sweep
     assert set(rec["grad_sync_ab"]) == {"rs_ag", "allreduce"} and set(rec["bucket_mb_sweep"]) == {"8.0", "2.0", "32.0"}
