@@ -20,7 +20,7 @@ for r in sel:
     busy += d
     n = r["Kernel_Name"]
     g = (int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
-    m = re.search(r"conv_gemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", n)
+    m = re.search(r"conv_gemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)", n)
     if m:
         n = "conv_gemm<%s,%s,ks%s,nbuf%s,pf%s,%s>" % (m.group(1), m.group(2), m.group(5), m.group(6), m.group(7),
                                                      ("fwd", "tdgrad", "dgrad3x3", "dgrad1x1")[int(m.group(8))])

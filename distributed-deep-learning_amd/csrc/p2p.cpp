@@ -53,16 +53,9 @@ using StreamGuard = c10::hip::HIPStreamGuardMasqueradingAsCUDA;
 using Event = at::cuda::CUDAEvent;
 
 ncclDataType_t nccl_dtype_of(const at::Tensor& t) {
-  switch (t.scalar_type()) {
-    case at::kFloat: return ncclFloat32;
-    case at::kDouble: return ncclFloat64;
-    case at::kHalf: return ncclFloat16;
-    case at::kBFloat16: return ncclBfloat16;
-    case at::kInt: return ncclInt32;
-    case at::kLong: return ncclInt64;
-    case at::kByte: return ncclUint8;
-    default: TORCH_CHECK(false, "p2p: unsupported dtype ", t.scalar_type());
-  }
+  const int code = ddl::rccl_dtype_code((int)t.scalar_type());
+  TORCH_CHECK(code >= 0, "p2p: unsupported dtype ", t.scalar_type());
+  return (ncclDataType_t)code;
 }
 
 // (peer's rank in the pipeline group, communicator, the peer's rank inside it, stream id, device index, device type)

@@ -34,18 +34,9 @@ struct DeviceScope {      // RCCL launches on the communicator's device; keep th
 };
 
 ncclDataType_t nccl_dtype(const at::Tensor& t) {
-  switch (t.scalar_type()) {
-    case at::kFloat: return ncclFloat32;
-    case at::kDouble: return ncclFloat64;
-    case at::kHalf: return ncclFloat16;
-    case at::kBFloat16: return ncclBfloat16;
-    case at::kInt: return ncclInt32;
-    case at::kLong: return ncclInt64;
-    case at::kByte: return ncclUint8;
-    case at::kChar: return ncclInt8;
-    case at::kBool: return ncclUint8;
-    default: TORCH_CHECK(false, "RcclComm: unsupported dtype ", t.scalar_type());
-  }
+  const int code = rccl_dtype_code((int)t.scalar_type());
+  TORCH_CHECK(code >= 0, "RcclComm: unsupported dtype ", t.scalar_type());
+  return (ncclDataType_t)code;
 }
 
 void check_tensor(const RcclComm& c, const at::Tensor& t, const char* what) {
@@ -55,6 +46,21 @@ void check_tensor(const RcclComm& c, const at::Tensor& t, const char* what) {
 }
 
 }  // namespace
+
+int rccl_dtype_code(int at_scalar_type) {
+  switch ((at::ScalarType)at_scalar_type) {
+    case at::kFloat: return (int)ncclFloat32;
+    case at::kDouble: return (int)ncclFloat64;
+    case at::kHalf: return (int)ncclFloat16;
+    case at::kBFloat16: return (int)ncclBfloat16;
+    case at::kInt: return (int)ncclInt32;
+    case at::kLong: return (int)ncclInt64;
+    case at::kByte: return (int)ncclUint8;
+    case at::kChar: return (int)ncclInt8;
+    case at::kBool: return (int)ncclUint8;
+    default: return -1;
+  }
+}
 
 std::string RcclComm::unique_id() {
   ncclUniqueId id;

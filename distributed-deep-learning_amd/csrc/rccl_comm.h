@@ -67,4 +67,7 @@ class RcclComm {
   int64_t launches_ = 0;
 };
 
+// element type of a tensor for RCCL (declared here, defined in rccl_comm.cpp; -1 = unsupported)
+int rccl_dtype_code(int at_scalar_type);
+
 }  // namespace ddl

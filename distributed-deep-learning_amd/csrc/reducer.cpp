@@ -56,6 +56,7 @@ class BucketReducer {
                                    (c10::DeviceType)comm_device_type)),    // the engine's communication stream
         direct_(std::move(direct)), test_hook_(test_hook), hook_spin_us_(hook_spin_us), skip_fence_(skip_fence) {
     TORCH_CHECK(direct_ != nullptr || pg_, "BucketReducer needs a process group or an owned communicator");
+    TORCH_CHECK(!test_hook_ || grad_.scalar_type() == at::kFloat, "test hook: fp32 gradient arena");
     if (direct_ != nullptr) {
       TORCH_CHECK(direct_->nranks() == world && direct_->rank() == rank, "owned communicator: rank / world differ from the group's");
       TORCH_CHECK(direct_->device() == grad_.device().index(), "owned communicator lives on another device");
