@@ -173,7 +173,7 @@ def direct_comm(ranks, device: torch.device, tag: str = "world", fresh: bool = F
         store.set(skey, uid)
     else:
         uid = store.get(skey)                      # blocks (store timeout) until member 0 has published it
-    dev_index = device.index if device.index is not None else torch.cuda.current_device()
+    dev_index = device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else 0)
     c = ext.RcclComm(bytes(uid), ranks.index(me), len(ranks), int(dev_index))
     if not fresh:
         _DIRECT[key] = c

@@ -41,6 +41,15 @@ class _HostRecv:
         self.dev.copy_(self.host)
 
 
+def link_pairs(me: int, neighbours: Sequence[int]) -> List[Tuple[int, int]]:
+    """The (lower, higher) group-rank pairs this rank shares a link communicator with, in the ONE global creation
+    order every rank follows (sorted).  `ncclCommInitRank` blocks until both members have joined, so two ranks must
+    never wait for each other in different inits: with every rank walking its pairs in ascending (lower, higher) order
+    the pair that is globally smallest among all unfinished ones always has both members at it
+    (`tests/test_dist.py::test_link_creation_order_never_deadlocks` simulates chains and rings)."""
+    return sorted({tuple(sorted((int(g), int(me)))) for g in neighbours if g is not None})
+
+
 class P2PChannel:
     def __init__(self, group, device, debug_sync: bool = False, profiler=None,
                  neighbours: Optional[Sequence[int]] = None, rccl: str = "auto", test_hook: int = 0,
@@ -67,7 +76,7 @@ class P2PChannel:
             links = []
             me = comm.get_rank(group)
             if neighbours and comm.rccl_transport(rccl) == "direct":
-                pairs = sorted({tuple(sorted((self._local(int(g)), me))) for g in neighbours if g is not None})
+                pairs = link_pairs(me, [self._local(int(g)) for g in neighbours if g is not None])
                 err, made = "", []
                 try:
                     for a, b in pairs:                       # one global creation order: (lower, higher) group rank

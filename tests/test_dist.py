@@ -277,3 +277,99 @@ def test_expected_orders():
     assert expected_order("1f1b", 0, 2, 4) == ["F0", "F1", "B0", "F2", "B1", "F3", "B2", "B3"]
     assert expected_order("1f1b", 1, 2, 4) == ["F0", "B0", "F1", "B1", "F2", "B2", "F3", "B3"]
     assert expected_order("1f1b", 0, 4, 2) == ["F0", "F1", "B0", "B1"]
+
+
+def test_link_creation_order_never_deadlocks():
+    """parallel/p2p.py link_pairs: every rank creates its per-neighbour communicators in ascending (lower, higher)
+    order.  Simulated with blocking semantics (a rank sits in its current init until the partner arrives at the SAME
+    pair): pipelines of 2..8 stages and rings of 2..8 ranks (the first-contact ladder) must all run to completion."""
+    from ddl.parallel.p2p import link_pairs
+
+    def run(world, neighbours_of):
+        todo = {r: list(link_pairs(r, neighbours_of(r))) for r in range(world)}
+        for _ in range(10 * world):
+            progressed = False
+            for r in range(world):
+                if not todo[r]:
+                    continue
+                a, b = todo[r][0]
+                peer = b if a == r else a
+                if peer == r:                                  # self link (one-GPU rehearsal)
+                    todo[r].pop(0)
+                    progressed = True
+                elif todo[peer] and todo[peer][0] == (a, b):   # both members sit in the same init: it completes
+                    todo[r].pop(0)
+                    todo[peer].pop(0)
+                    progressed = True
+            if not any(todo.values()):
+                return True
+            if not progressed:
+                return False
+        return False
+
+    for S in range(2, 9):
+        assert run(S, lambda r, S=S: [x for x in (r - 1, r + 1) if 0 <= x < S]), f"pipeline of {S} stages deadlocks"
+        assert run(S, lambda r, S=S: [(r + 1) % S, (r - 1) % S]), f"ring of {S} ranks deadlocks"
+    assert link_pairs(0, [0]) == [(0, 0)]
+    assert link_pairs(3, [2, 4]) == [(2, 3), (3, 4)] and link_pairs(0, [1, 7]) == [(0, 1), (0, 7)]
+
+
+def _direct_comm_worker(rank, world):
+    """comm.direct_comm / direct_comm_or_fallback rendezvous on CPU with a stand-in extension: member 0's unique id
+    must reach every member through the c10d store byte for byte (NUL bytes included), repeated creations use fresh
+    keys, the cache returns the same object, and a member that fails makes EVERY member fall back together."""
+    import os
+    from ddl import comm, ops
+
+    class FakeComm:
+        def __init__(self, uid, r, n, dev):
+            if os.environ.get("FAKE_RCCL_FAIL_RANK") == str(r):
+                raise RuntimeError("ncclCommInitRank failed (simulated)")
+            self.uid, self.rank, self.nranks, self.device, self.aborted = bytes(uid), r, n, dev, False
+
+        def abort(self):
+            self.aborted = True
+
+        def destroy(self):
+            pass
+
+    class FakeExt:
+        RcclComm = FakeComm
+        calls = 0
+
+        @staticmethod
+        def rccl_unique_id():
+            FakeExt.calls += 1
+            return bytes([0, 255, 0, FakeExt.calls]) + os.urandom(124)
+
+    real = ops.require_ext
+    ops.require_ext = lambda: FakeExt
+    try:
+        dev = torch.device("cpu")
+        c1 = comm.direct_comm(list(range(world)), dev, tag="t")
+        assert (c1.rank, c1.nranks) == (rank, world) and len(c1.uid) == 128 and c1.uid[:3] == b"\x00\xff\x00"
+        ids = [None] * world
+        dist.all_gather_object(ids, c1.uid)
+        assert all(i == ids[0] for i in ids)                              # every member joined with member 0's id
+        assert comm.direct_comm(list(range(world)), dev, tag="t") is c1     # cached
+        c2 = comm.direct_comm(list(range(world)), dev, tag="t", fresh=True)
+        ids2 = [None] * world
+        dist.all_gather_object(ids2, c2.uid)
+        assert all(i == ids2[0] for i in ids2) and ids2[0] != ids[0]        # a fresh key, a fresh id
+        sub = comm.direct_comm([0, world - 1], dev, tag="pair") if rank in (0, world - 1) else None
+        if sub is not None:
+            assert sub.nranks == (2 if world > 1 else 1) and sub.rank == (0 if rank == 0 else 1)
+        # collective fallback: rank 1 fails -> nobody keeps a communicator
+        os.environ["FAKE_RCCL_FAIL_RANK"] = "1"
+        got = comm.direct_comm_or_fallback(list(range(world)), dev, "failing", None, who="test")
+        assert got is None and ("failing", tuple(range(world))) not in comm._DIRECT
+        os.environ.pop("FAKE_RCCL_FAIL_RANK")
+        ok = comm.direct_comm_or_fallback(list(range(world)), dev, "fine", None, who="test")
+        assert ok is not None and ok.nranks == world
+    finally:
+        ops.require_ext = real
+        comm._DIRECT.clear()
+
+
+def test_owned_communicator_rendezvous_through_the_store():
+    run_distributed(_direct_comm_worker, 3, timeout=120)
