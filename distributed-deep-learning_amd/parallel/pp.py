@@ -179,6 +179,14 @@ class PipelineStage:
         # forward lanes: forward i on forward stream i % n_fwd, BN running statistics handed off in micro-batch order
         # through per-micro-batch scratch copies (native_densenet "buffer lanes"); arithmetic applies in eager steps too
         self.n_fwd = max(1, int(n_fwd_lanes)) if (self.n_lanes > 1 and hasattr(module, "ensure_buffer_lanes")) else 1
+        # borrowed lanes: once the step's last forwards are out, the forward streams idle while the remaining backwards
+        # queue up on the backward streams (lane timeline of round 3: B4 ran ALONE for 2.5 ms of a 13.9 ms step).  The
+        # last `n_fwd` backwards therefore run on the forward stream of their own micro-batch (no later forward is ever
+        # issued on it) and accumulate into gradient arenas of their own - same fixed lane arithmetic in eager steps.
+        self.borrow = self.n_lanes > 1 and self.n_fwd > 1 and knob("DDL_LANE_BORROW", "1") == "1"
+        if self.borrow:
+            module.ensure_grad_lanes(self.n_lanes + self.n_fwd)
+        self._n_mb = 0
         self.fwd_streams: List = []
         self.bwd_streams: List = []
         self._lanes_live = False          # True between begin_step and join_lanes of a graphed training step
@@ -248,6 +256,7 @@ class PipelineStage:
     def prepare_step(self, n_microbatches: int, train: bool) -> None:
         """Called by the schedule before ``begin_step`` (eager and graphed steps alike)."""
         self._handoff = self.n_fwd > 1 and train
+        self._n_mb = int(n_microbatches)
         if self._handoff:
             self.module.ensure_buffer_lanes(n_microbatches)
 
@@ -278,7 +287,13 @@ class PipelineStage:
             return self.fwd_streams[i % self.n_fwd]
         if last and self.join_before_last:
             return None
+        if self._borrowed(i):
+            return self.fwd_streams[i % self.n_fwd]
         return self.bwd_streams[i % self.n_lanes]
+
+    def _borrowed(self, i: int) -> bool:
+        """Backward ``i`` is one of the step's last ``n_fwd`` backwards: it runs on its micro-batch's forward stream."""
+        return self.borrow and i >= self._n_mb - self.n_fwd
 
     def lane_ctx(self, stream):
         return torch.cuda.stream(stream) if stream is not None else nullcontext()
@@ -311,6 +326,8 @@ class PipelineStage:
         """Gradient arena micro-batch ``i`` accumulates into."""
         if self.n_lanes == 1 or (last and self.join_before_last):
             return 0
+        if self._borrowed(i):
+            return self.n_lanes + i % self.n_fwd
         return i % self.n_lanes
 
     def backward(self, i: int, scale: float, last: bool) -> None:

@@ -104,17 +104,19 @@ def tables(t_single_ms: float = 8.56, t_ddp1_ms: float = 8.75, adam_ms: float = 
                        f"{r['comm_busy_ms']:>13.3f} {r['comm_exposed_ms']:>16.3f}")
     out.append("\n# pipeline / hybrid at the reference's shapes and at the throughput preset - MODELLED")
     out.append(f"{'mode':>28} {'GPUs':>5} {'step ms':>9} {'samples/s':>11} {'vs 1 GPU batch 30':>18}")
-    # measured one-stage numbers (profiles/r3): 5 x 6 parity shape 13.86 ms per 30 images on ONE stage holding the whole
+    # measured one-stage numbers (profiles/r3): 5 x 6 parity shape 12.24 ms per 30 images on ONE stage holding the whole
     # model -> a balanced 2-stage pipeline runs ~half of that per micro-batch slot
-    t_mb_parity = 13.86 / 5 / 2
+    t_mb_parity = 12.24 / 5 / 2
     pp2 = pipeline_step_ms(2, 5, t_mb_parity, 6 * 14 * 14 * 256 * 4, link)
     out.append(f"{'pp 2 stages, 5 x 6 (parity)':>28} {2:>5} {pp2:>9.2f} {30 / pp2 * 1e3:>11.0f} {30 / pp2 * 1e3 / base:>17.2f}x")
-    t_mb_mi = 68.8 / 8 / 2                                   # preset mi355x: 8 x 30 on one stage = 68.8 ms (r2)
+    t_mb_mi = 49.5 / 8 / 2                                   # preset mi355x: 8 x 30 on one stage = 49.5 ms (r3, lanes)
     pp2m = pipeline_step_ms(2, 8, t_mb_mi, 30 * 14 * 14 * 256 * 4, link)
     out.append(f"{'pp 2 stages, 8 x 30 (mi355x)':>28} {2:>5} {pp2m:>9.2f} {240 / pp2m * 1e3:>11.0f} {240 / pp2m * 1e3 / base:>17.2f}x")
-    t_mb_h = 10.42 / 5 / 2                                   # hybrid parity: 5 x 2 on one stage = 10.42 ms per 10 images
+    t_mb_h = 8.99 / 5 / 2                                    # hybrid parity: 5 x 2 on one stage = 8.99 ms per 10 images
     hy = pipeline_step_ms(2, 5, t_mb_h, 2 * 14 * 14 * 256 * 4, link) + rs_ag_ms(PARAM_BYTES / 2 / 4, 4, link)
     out.append(f"{'dp4 x pp2, 5 x 2 (parity)':>28} {8:>5} {hy:>9.2f} {40 / hy * 1e3:>11.0f} {40 / hy * 1e3 / base:>17.2f}x")
+    out.append("(pipeline rows: a coarse UPPER bound - they assume a stage holding half of the model runs a micro-batch in half of "
+               "the one-stage time and keeps its lane concurrency; the DDP rows rest on firmer ground)")
     out.append("\n(the reference on its own hardware: ddp 1.48x, pp 0.82x, ddp x pp 0.67x of its single-GPU rate - BASELINE.md)")
     return "\n".join(out)
 
