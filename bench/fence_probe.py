@@ -34,10 +34,21 @@ SPIN = 20000.0          # us: far longer than any launch gap, so a missing fence
 N = 1 << 16
 
 
-def report(engine, transport, case, got, want, expect_ok):
+def beside(stream) -> bool:
+    """True if `stream` really runs beside the compute stream.  Two streams that share a hardware queue are
+    serialised on the device, so a missing fence between them can never show: a negative control on such a pair is
+    INCONCLUSIVE, not a failure of the engine (utils/streams.py picks streams on other queues, but a box whose queues
+    are all taken may not have one)."""
+    return bool(run_concurrently(stream, torch.cuda.current_stream(dev)))
+
+
+def report(engine, transport, case, got, want, expect_ok, concurrent=True):
     ok = got == want
-    print(f"FENCE {engine} {transport} {case} got={got} want={want} {'OK' if ok else 'DIFFERS'}"
-          f"{'' if ok == expect_ok else '  <-- UNEXPECTED'}", flush=True)
+    verdict = "OK" if ok else "DIFFERS"
+    if not expect_ok and ok and not concurrent:
+        verdict = "INCONCLUSIVE"
+    print(f"FENCE {engine} {transport} {case} got={got} want={want} {verdict}"
+          f"{'' if (ok == expect_ok or verdict == 'INCONCLUSIVE') else '  <-- UNEXPECTED'}", flush=True)
 
 
 def reducer_case(transport, case, skip, delay, hook_spin):
@@ -63,7 +74,7 @@ def reducer_case(transport, case, skip, delay, hook_spin):
     red.finish()                            # grads-ready: compute waits for the comm stream
     out = g.clone()                         # the "optimizer" reads on the compute stream
     torch.cuda.synchronize()
-    report("reducer", transport, case, (float(out.min()), float(out.max())), (0.5, 0.5), skip == 0)
+    report("reducer", transport, case, (float(out.min()), float(out.max())), (0.5, 0.5), skip == 0, beside(cs))
 
 
 def p2p_case(transport, case, skip, delay, hook_spin):
@@ -85,7 +96,8 @@ def p2p_case(transport, case, skip, delay, hook_spin):
         out = inbox.clone()
         chan.drain()
         torch.cuda.synchronize()
-        report("p2p", transport, case, (float(out.min()), float(out.max())), (0.5, 0.5), skip == 0)
+        report("p2p", transport, case, (float(out.min()), float(out.max())), (0.5, 0.5), skip == 0,
+               all(beside(st) for st in chan.streams[-1:]))
     else:
         # slot reuse across steps: step t's consumer is LATE (spin in front of it); step t+1's receive into the same
         # slot is pre-posted right after `fence()`
@@ -98,7 +110,8 @@ def p2p_case(transport, case, skip, delay, hook_spin):
         chan.wait(t)
         chan.drain()
         torch.cuda.synchronize()
-        report("p2p", transport, case, (float(seen.min()), float(seen.max())), (7.0, 7.0), skip == 0)
+        report("p2p", transport, case, (float(seen.min()), float(seen.max())), (7.0, 7.0), skip == 0,
+               all(beside(st) for st in chan.streams[-1:]))
 
 
 def buffers_case(transport, case, skip, delay, hook_spin):
@@ -120,7 +133,7 @@ def buffers_case(transport, case, skip, delay, hook_spin):
     eng.finish_grad_sync()                  #   missing buffers-done fence (same communication stream)
     out = ff.clone()                        # the next forward reads the buffers
     torch.cuda.synchronize()
-    report("buffers", transport, case, (float(out.min()), float(out.max())), (0.5, 0.5), skip == "")
+    report("buffers", transport, case, (float(out.min()), float(out.max())), (0.5, 0.5), skip == "", beside(eng.comm_stream))
 
 
 def steps_case():
@@ -150,8 +163,8 @@ def steps_case():
         finally:
             dp_mod.DataParallelEngine.__init__ = orig
         strat.model.train()
-        print(f"steps/{name}: comm stream beside the compute stream: "
-              f"{run_concurrently(strat.dp.comm_stream, torch.cuda.current_stream(dev))}", flush=True)
+        conc = beside(strat.dp.comm_stream)
+        print(f"steps/{name}: comm stream beside the compute stream: {conc}", flush=True)
         g = torch.Generator().manual_seed(9)
         for step in range(5):
             x = torch.randint(0, 256, (8, 3, 64, 64), dtype=torch.uint8, generator=g).to(dev)
@@ -159,13 +172,15 @@ def steps_case():
             ext.test_spin(3000.0, dev.index)        # the step's compute starts late: an unfenced hook runs ahead of it
             strat.train_step(x, y, 8)
         torch.cuda.synchronize()
-        finals[name] = (strat.arena.flat_param.clone(), strat.model.flat_buffers.flat_float.clone())
+        finals[name] = (strat.arena.flat_param.clone(), strat.model.flat_buffers.flat_float.clone(), conc)
         del strat
     ref = finals["overlapped"]
     for name in ("debug-sync", "no-bucket-ready", "no-grads-ready"):
         same = bool(torch.equal(ref[0], finals[name][0]) and torch.equal(ref[1], finals[name][1]))
-        print(f"FENCE steps direct overlapped-vs-{name} got={'same' if same else 'different'} want=same "
-              f"{'OK' if same else 'DIFFERS'}", flush=True)
+        verdict = "OK" if same else "DIFFERS"
+        if same and name != "debug-sync" and not finals[name][2]:
+            verdict = "INCONCLUSIVE"
+        print(f"FENCE steps direct overlapped-vs-{name} got={'same' if same else 'different'} want=same {verdict}", flush=True)
 
 
 if part in ("reducer", "all"):
