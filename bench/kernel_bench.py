@@ -29,6 +29,7 @@ a = ap.parse_args()
 if a.cfg >= 0:
     a.bm = 1000 + a.cfg
 a.bf16 = int(a.bf16) if a.prec is None else a.prec
+WPREC = 1 if a.bf16 == 1 else 0          # weight gradients: bf16 MFMA only in the bf16 mode
 ext = ops.require_ext()
 dev = torch.device("cuda", 0)
 B = a.batch
@@ -122,12 +123,12 @@ for (blk, H, Cl, Cf) in [("b1", 56, 160, 256), ("b2", 28, 320, 512), ("b3", 14, 
     cases.append((f"{blk}_dgrad1x1_N{Cl}", 2.0 * M * Cl * 128, f4))
 
     def f5(M=M, g2=g2, h=h, k=k, buf=buf, Cl=Cl, sc=sc, sh=sh, gw1=gw1, H=H):
-        ext.conv_wgrad(g2, h, k[0], k[1], k[2], buf[:, :Cl], sc, sh, True, M, H, H, 1, gw1, a.min_rows, force_sub=a.sub, **WQ)
+        ext.conv_wgrad(g2, h, k[0], k[1], k[2], buf[:, :Cl], sc, sh, True, M, H, H, 1, gw1, a.min_rows, force_sub=a.sub, prec=WPREC, **WQ)
     cases.append((f"{blk}_wgrad1x1_C{Cl}", 2.0 * M * Cl * 128, f5))
 
     def f6(M=M, dbuf=dbuf, buf=buf, Cl=Cl, ones=ones, sc=sc, sh=sh, h=h, gw2=gw2, H=H):
         ext.conv_wgrad(dbuf[:, Cl:Cl + 32], buf[:, Cl:Cl + 32], ones[:32], sc[:32], sh[:32], h, sc, sh, True, M, H, H,
-                       9, gw2, a.min_rows, **WQ)
+                       9, gw2, a.min_rows, prec=WPREC, **WQ)
     cases.append((f"{blk}_wgrad3x3", 2.0 * M * 1152 * 32, f6))
 
 for (blk, H, Cl, Cf) in [("b1", 56, 64, 256), ("b1", 56, 96, 256), ("b1", 56, 224, 256), ("b2", 28, 160, 512), ("b2", 28, 480, 512),
@@ -139,7 +140,7 @@ for (blk, H, Cl, Cf) in [("b1", 56, 64, 256), ("b1", 56, 96, 256), ("b1", 56, 22
     gw1 = torch.zeros(128, Cl, device=dev)
 
     def f5x(M=M, g2=g2, h=h, k=k, buf=buf, Cl=Cl, sc=sc, sh=sh, gw1=gw1, H=H):
-        ext.conv_wgrad(g2, h, k[0], k[1], k[2], buf[:, :Cl], sc, sh, True, M, H, H, 1, gw1, a.min_rows, force_sub=a.sub, **WQ)
+        ext.conv_wgrad(g2, h, k[0], k[1], k[2], buf[:, :Cl], sc, sh, True, M, H, H, 1, gw1, a.min_rows, force_sub=a.sub, prec=WPREC, **WQ)
     cases.append((f"{blk}_wgrad1x1_C{Cl}", 2.0 * M * Cl * 128, f5x))
 
 PHASES = ["entry", "loads issued + tables", "first slab in LDS", "K loop", "K-split combine", "epilogue stores issued",

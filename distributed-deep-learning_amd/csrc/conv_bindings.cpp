@@ -313,17 +313,19 @@ class SlabQueue {
 void conv_wgrad(const at::Tensor& d0, const OptT& d1, const OptT& ds0, const OptT& ds1, const OptT& ds2,
                 const at::Tensor& a0, const OptT& as0, const OptT& as2, bool a_relu, int64_t M, int64_t H,
                 int64_t W, int64_t taps, at::Tensor dW, int64_t min_rows, const OptT& k_acc, const OptT& k_mean,
-                const OptT& k_rstd, const OptT& k_scale, double k_count, SlabQueue* queue, int64_t force_sub) {
+                const OptT& k_rstd, const OptT& k_scale, double k_count, SlabQueue* queue, int64_t force_sub,
+                int64_t prec) {
   ddl::DeviceGuard guard(d0.device());
   const int64_t N = d0.size(1), C = a0.size(1);
   TORCH_CHECK(taps == 1 || taps == 9, "taps must be 1 or 9");
+  TORCH_CHECK(prec == 0 || prec == 1, "conv_wgrad: prec 0 (fp32 MFMA) or 1 (bf16 MFMA inputs)");
   TORCH_CHECK(M > 0 && M < (1LL << 31), "bad M");
   ddl::WgradParams p{};
   p.d = make_src(d0, d1, ds0, ds1, ds2, false, M, N, "wgrad dO", k_acc.has_value());
   p.fk = make_fk(k_acc, k_mean, k_rstd, k_scale, c10::nullopt, c10::nullopt, k_count, N);
   if (p.fk.acc != nullptr) { TORCH_CHECK(taps == 1 && d1.has_value(), "fused k: 1x1 weight gradient with two dO sources"); }
   p.a = make_src(a0, c10::nullopt, as0, c10::nullopt, as2, a_relu, M, C, "wgrad activation");
-  p.M = (int)M; p.C = (int)C; p.N = (int)N; p.H = (int)H; p.W = (int)W; p.taps = (int)taps;
+  p.M = (int)M; p.C = (int)C; p.N = (int)N; p.H = (int)H; p.W = (int)W; p.taps = (int)taps; p.bf16 = (int)prec;
   if (taps == 9) {
     TORCH_CHECK(N <= 32 && N % 4 == 0, "3x3 wgrad: N <= 32 output channels");
     TORCH_CHECK(H > 0 && W > 0 && M % (H * W) == 0, "M must be a whole number of HxW images");
@@ -363,8 +365,9 @@ void conv_wgrad(const at::Tensor& d0, const OptT& d1, const OptT& ds0, const Opt
 void conv_wgrad_group(int64_t taps, std::vector<at::Tensor> d0, std::vector<at::Tensor> d1, std::vector<at::Tensor> ds0,
                       std::vector<at::Tensor> ds1, std::vector<at::Tensor> ds2, std::vector<at::Tensor> a0,
                       std::vector<at::Tensor> as0, std::vector<at::Tensor> as2, std::vector<at::Tensor> dW, int64_t M,
-                      int64_t H, int64_t W, SlabQueue* queue) {
+                      int64_t H, int64_t W, SlabQueue* queue, int64_t prec) {
   const size_t n = d0.size();
+  TORCH_CHECK(prec == 0 || prec == 1, "conv_wgrad_group: prec 0 (fp32 MFMA) or 1 (bf16 MFMA inputs)");
   TORCH_CHECK(n >= 1 && n <= (size_t)ddl::kMaxWgradGroup, "conv_wgrad_group: 1..", ddl::kMaxWgradGroup, " layers");
   TORCH_CHECK(d1.size() == n && ds0.size() == n && ds1.size() == n && ds2.size() == n && a0.size() == n &&
                   as0.size() == n && as2.size() == n && dW.size() == n, "conv_wgrad_group: list lengths differ");
@@ -378,7 +381,7 @@ void conv_wgrad_group(int64_t taps, std::vector<at::Tensor> d0, std::vector<at::
     TORCH_CHECK(H > 0 && W > 0 && M % (H * W) == 0, "M must be a whole number of HxW images");
   }
   ddl::WgradGroupParams g{};
-  g.n = (int)n; g.M = (int)M; g.N = (int)N; g.H = (int)H; g.W = (int)W; g.taps = (int)taps; g.a_relu = 1;
+  g.n = (int)n; g.M = (int)M; g.N = (int)N; g.H = (int)H; g.W = (int)W; g.taps = (int)taps; g.a_relu = 1; g.bf16 = (int)prec;
   int64_t tiles = 0, slab_elems = 0;
   for (size_t i = 0; i < n; ++i) {
     const int64_t C = a0[i].size(1);
@@ -558,11 +561,11 @@ void register_conv_ops(pybind11::module_& m) {
         pybind11::arg("H"), pybind11::arg("W"), pybind11::arg("taps"), pybind11::arg("dW"), pybind11::arg("min_rows"),
         pybind11::arg("k_acc") = c10::nullopt, pybind11::arg("k_mean") = c10::nullopt,
         pybind11::arg("k_rstd") = c10::nullopt, pybind11::arg("k_scale") = c10::nullopt, pybind11::arg("k_count") = 0.0,
-        pybind11::arg("queue") = nullptr, pybind11::arg("force_sub") = 0);
+        pybind11::arg("queue") = nullptr, pybind11::arg("force_sub") = 0, pybind11::arg("prec") = 0);
   m.def("conv_wgrad_group", &conv_wgrad_group, "weight gradients of up to 24 dense layers in one launch",
         pybind11::arg("taps"), pybind11::arg("d0"), pybind11::arg("d1"), pybind11::arg("ds0"), pybind11::arg("ds1"),
         pybind11::arg("ds2"), pybind11::arg("a0"), pybind11::arg("as0"), pybind11::arg("as2"), pybind11::arg("dW"),
-        pybind11::arg("M"), pybind11::arg("H"), pybind11::arg("W"), pybind11::arg("queue"));
+        pybind11::arg("M"), pybind11::arg("H"), pybind11::arg("W"), pybind11::arg("queue"), pybind11::arg("prec") = 0);
   m.attr("MAX_WGRAD_GROUP") = pybind11::int_(ddl::kMaxWgradGroup);
   pybind11::class_<SlabQueue>(m, "SlabQueue")
       .def(pybind11::init<>())

@@ -154,6 +154,7 @@ struct WgradParams {
   int S;
   int sub;            // 1x1: 32-column sub-tiles per workgroup tile (1..4) and the number of channel tiles
   int ctiles;
+  int bf16;           // 1: operands rounded to bf16 at the LDS write, v_mfma_f32_32x32x16_bf16 via transposing LDS reads
 };
 
 // layer-grouped weight gradients (conv_wgrad.hip: wgrad_group_kernel): one entry per dense layer; M, N, the
@@ -181,6 +182,7 @@ struct WgradGroupParams {
   int S, rows_per_wg;
   int ld_d0, ld_d1, ld_a0;
   int a_relu;
+  int bf16;           // as WgradParams::bf16
 };
 
 // deferred slab reductions: dW += sum over S slabs, many weight gradients in one launch (conv_wgrad.hip)

@@ -16,6 +16,14 @@
 // MFMA mapping (v_mfma_f32_32x32x2_f32): D[i = n][j = c] += sum_m dO[m][n] * A[m][c]; both LDS
 // tiles keep the pixel axis as rows, so lane (i, h) reads row 2s+h, column i: 32 consecutive
 // floats per half-wave - conflict-free ds_read_b32.
+//
+// BF = true (`--dtype bf16`): the same kernels on v_mfma_f32_32x32x16_bf16.  Both operands have the REDUCTION axis
+// (pixels) as LDS rows, but the bf16 MFMA wants 8 consecutive k per lane - i.e. a column of the tile.  gfx950's
+// `ds_read_b64_tr_b16` does exactly that transposition on the way out of LDS: per 16 lanes a 4-row x 16-column block,
+// lane 4q+p supplies the address of row q / columns 4p..4p+3 and receives column (lane % 16) of the four rows.  Two
+// such reads give a lane its 8 k-values; tiles are rounded to bf16 (RNE) when they are written, after the fused
+// prologue, and stay pixel-major - no transposing store, no second layout.  Row strides are 64 B (mod 256 B) so the
+// four rows of a block fall into disjoint bank groups (checked on the device: bench/r3/tr_read_check.hip).
 #include <cstdlib>
 
 #include "conv_params.h"
@@ -96,6 +104,16 @@ __device__ __forceinline__ f32x4 pix_apply(const RawPix& r, const ColAffine& k) 
 
 constexpr int RK = 32;   // pixels per slab step
 
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+// 8 consecutive rows (k) of one column of a row-major bf16 LDS tile, `p` = this lane's block address (see above)
+__device__ __forceinline__ bf16x8 lds_tr8(const __bf16* p, int ld) {
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * ld));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+constexpr int bf_lda(int sub) { return 32 * sub + (sub == 4 ? 32 : 0); }   // bf16 row stride of the 1x1 activation tile
+constexpr int kBfLdd = 160;                                                // ... of the 1x1 dO tile (128 + 32)
+
 // XCD-aware work order.  Workgroups are dealt round-robin over the 8 XCDs (one L2 each); the T
 // workgroups that share a pixel chunk (the channel tiles of the 1x1 kernel, the three filter rows of
 // the 3x3 kernel) re-read the same dO / activation rows, so they are given linear ids that agree
@@ -119,11 +137,14 @@ __device__ __forceinline__ bool xcd_group(int id, int T, int S, int& t, int& chu
 // 32-column tiles a 14x14 layer needs 4-5x fewer pixel chunks S for the same number of workgroups.
 // grid = (c tiles x n tiles x S), XCD-grouped.
 // ---------------------------------------------------------------------------------------------
-template <int SUB, bool DTWO, int PF>
+template <int SUB, bool DTWO, int PF, bool BF>
 __device__ __forceinline__ void wgrad1x1_body(const WgradParams& p, const int bid, float* smem) {
   constexpr int TC = 32 * SUB;
+  constexpr int LDD = kBfLdd, LDA = bf_lda(SUB);
   float* Ds = smem;                     // [2][RK][128]
   float* As = smem + 2 * RK * 128;      // [2][RK][TC]
+  __bf16* Dh = reinterpret_cast<__bf16*>(smem);    // BF: [2][RK][LDD]
+  __bf16* Ah = Dh + 2 * RK * LDD;                  //     [2][RK][LDA]
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar wave index
   const int li = lane & 31, lh = lane >> 5;
   const int ctiles = p.ctiles, ntiles = (p.N + 127) / 128;
@@ -170,6 +191,17 @@ __device__ __forceinline__ void wgrad1x1_body(const WgradParams& p, const int bi
       R.a[j] = pix_fetch<false>(da, m, c0 + 32 * j + aq, m < me && c0 + 32 * j + aq < p.C);
   };
   auto store_step = [&](int buf, const Raw& R) {
+    if constexpr (BF) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<bf16x4*>(Dh + buf * RK * LDD + ((tid >> 5) + 8 * i) * LDD + q) =
+            __builtin_convertvector(pix_apply<DTWO>(R.d[i], kd), bf16x4);
+#pragma unroll
+      for (int j = 0; j < SUB; ++j)
+        *reinterpret_cast<bf16x4*>(Ah + buf * RK * LDA + ar * LDA + 32 * j + aq) =
+            __builtin_convertvector(pix_apply<false>(R.a[j], ka[j]), bf16x4);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       *reinterpret_cast<f32x4*>(Ds + buf * RK * 128 + ((tid >> 5) + 8 * i) * 128 + q) = pix_apply<DTWO>(R.d[i], kd);
@@ -188,7 +220,22 @@ __device__ __forceinline__ void wgrad1x1_body(const WgradParams& p, const int bi
 #pragma unroll
   for (int j = 0; j < SUB; ++j) live[j] = c0 + 32 * j < p.C;
 
+  // transposing-read block address of this lane: row 8*lh + q, columns 16*(half of li) + 4p
+  const int trow = 8 * lh + ((lane & 15) >> 2), tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   auto compute = [&](int buf) {
+    if constexpr (BF) {
+#pragma unroll
+      for (int ks = 0; ks < RK / 16; ++ks) {
+        const bf16x8 d = lds_tr8(Dh + buf * RK * LDD + (16 * ks + trow) * LDD + wid * 32 + tcol, LDD);
+        bf16x8 av[SUB];
+#pragma unroll
+        for (int j = 0; j < SUB; ++j) av[j] = lds_tr8(Ah + buf * RK * LDA + (16 * ks + trow) * LDA + 32 * j + tcol, LDA);
+#pragma unroll
+        for (int j = 0; j < SUB; ++j)
+          if (live[j]) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d, av[j], acc[j], 0, 0, 0);
+      }
+      return;
+    }
     const float* Db = Ds + buf * RK * 128 + wid * 32 + li;
     const float* Ab = As + buf * RK * TC + li;
 #pragma unroll
@@ -259,19 +306,24 @@ __device__ __forceinline__ void wgrad1x1_body(const WgradParams& p, const int bi
   }
 }
 
-template <int SUB, bool DTWO, int PF>
+template <int SUB, bool DTWO, int PF, bool BF>
 __global__ void __launch_bounds__(256, 2) wgrad1x1_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  wgrad1x1_body<SUB, DTWO, PF>(p, (int)blockIdx.x, smem);
+  wgrad1x1_body<SUB, DTWO, PF, BF>(p, (int)blockIdx.x, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
 // 3x3 (stride 1, pad 1), N = 32 output channels, C = 128 input channels per workgroup column
 // tile.  grid = (S, 3 (dy), C/128).  Wave w owns channels [32w, 32w+32) for the three dx taps.
 // ---------------------------------------------------------------------------------------------
-template <bool DTWO>
+// BF: the border mask of a tap depends on the PIXEL, which is the k axis a lane holds 8 of - so instead of masking
+// operands in the loop the dO tile is staged three times, once per dx tap with that tap's mask applied (3 x 2 KB).
+template <bool DTWO, bool BF>
 __device__ __forceinline__ void wgrad3x3_body(const WgradParams& p, const int bid, float* smem) {
   constexpr int AR = RK + 2;                       // activation rows staged per step (dx halo)
+  constexpr int LDD = 32, LDA = 160;               // BF row strides (elements): 64 B and 320 B
+  __bf16* Dh = reinterpret_cast<__bf16*>(smem);    // BF: [2][3][RK][LDD]
+  __bf16* Ah = Dh + 2 * 3 * RK * LDD;              //     [2][AR][LDA]
   float* Ds = smem;                                // [2][RK][32]
   float* As = smem + 2 * RK * 32;                  // [2][AR][128]
   int* Fl = reinterpret_cast<int*>(smem + 2 * RK * 32 + 2 * AR * 128);   // [2][RK]
@@ -307,8 +359,8 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradParams& p, const int bi
       a_raw[i] = pix_fetch<false>(da, ms, cbase + 4 * (f & 31),
                            r < AR && ms >= 0 && ms < p.M && cbase + 4 * (f & 31) < p.C);
     }
-    if (tid < RK) {
-      const int m = mrow + tid;
+    if (BF || tid < RK) {                         // BF: every thread, for the dO row it stages
+      const int m = mrow + (BF ? (tid >> 3) : tid);
       int fl = 0;
       if (m < me) {
         const int rem = m % HW;
@@ -323,6 +375,21 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradParams& p, const int bi
     }
   };
   auto store_step = [&](int buf) {
+    if constexpr (BF) {
+      const f32x4 v = pix_apply<DTWO>(d_raw, kd), z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        *reinterpret_cast<bf16x4*>(Dh + ((buf * 3 + t) * RK + (tid >> 3)) * LDD + 4 * (tid & 7)) =
+            __builtin_convertvector(((fl_reg >> t) & 1) ? v : z, bf16x4);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int f = tid + i * 256;
+        if ((f >> 5) < AR)
+          *reinterpret_cast<bf16x4*>(Ah + (buf * AR + (f >> 5)) * LDA + 4 * (f & 31)) =
+              __builtin_convertvector(pix_apply<false>(a_raw[i], ka), bf16x4);
+      }
+      return;
+    }
     *reinterpret_cast<f32x4*>(Ds + buf * RK * 32 + (tid >> 3) * 32 + 4 * (tid & 7)) = pix_apply<DTWO>(d_raw, kd);
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -347,19 +414,34 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradParams& p, const int bi
   for (int st = 0; st < steps; ++st) {
     const int buf = st & 1;
     if (st + 1 < steps) load_step(st + 1);
-    const float* Db = Ds + buf * RK * 32 + li;
-    const float* Ab = As + buf * AR * 128 + wid * 32 + li;
-    const int* Fb = Fl + buf * RK;
+    if constexpr (BF) {
+      const int trow = 8 * lh + ((lane & 15) >> 2), tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 #pragma unroll
-    for (int s = 0; s < RK / 2; ++s) {
-      const int r = 2 * s + lh;
-      const float d = Db[r * 32];
-      const int fl = Fb[r];
+      for (int ks = 0; ks < RK / 16; ++ks) {
+        bf16x8 d[3], a[3];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        float a = Ab[(r + t) * 128];
-        a = ((fl >> t) & 1) ? a : 0.f;
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(d, a, acc[t], 0, 0, 0);
+        for (int t = 0; t < 3; ++t) {
+          d[t] = lds_tr8(Dh + ((buf * 3 + t) * RK + 16 * ks + trow) * LDD + tcol, LDD);
+          a[t] = lds_tr8(Ah + (buf * AR + 16 * ks + trow + t) * LDA + wid * 32 + tcol, LDA);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d[t], a[t], acc[t], 0, 0, 0);
+      }
+    } else {
+      const float* Db = Ds + buf * RK * 32 + li;
+      const float* Ab = As + buf * AR * 128 + wid * 32 + li;
+      const int* Fb = Fl + buf * RK;
+#pragma unroll
+      for (int s = 0; s < RK / 2; ++s) {
+        const int r = 2 * s + lh;
+        const float d = Db[r * 32];
+        const int fl = Fb[r];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          float a = Ab[(r + t) * 128];
+          a = ((fl >> t) & 1) ? a : 0.f;
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(d, a, acc[t], 0, 0, 0);
+        }
       }
     }
     if (st + 1 < steps) store_step(buf ^ 1);
@@ -379,10 +461,10 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradParams& p, const int bi
   }
 }
 
-template <bool DTWO>
+template <bool DTWO, bool BF>
 __global__ void __launch_bounds__(256) wgrad3x3_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  wgrad3x3_body<DTWO>(p, (int)blockIdx.x, smem);
+  wgrad3x3_body<DTWO, BF>(p, (int)blockIdx.x, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -394,7 +476,7 @@ __global__ void __launch_bounds__(256) wgrad3x3_kernel(const WgradParams p) {
 // (no 100-way split of 5880 pixels), a few hundred workgroups of real work and G times fewer launches.
 // Workgroup -> (layer entry, tile, pixel chunk); entries share M, N, the leading dimensions and the chunking.
 // ---------------------------------------------------------------------------------------------
-template <int TAPS>
+template <int TAPS, bool BF>
 __global__ void __launch_bounds__(256, 2) wgrad_group_kernel(const WgradGroupParams g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int e = 0;
@@ -416,8 +498,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_group_kernel(const WgradGroupPar
   p.M = g.M; p.C = en.C; p.N = g.N; p.H = g.H; p.W = g.W; p.taps = TAPS;
   p.rows_per_wg = g.rows_per_wg; p.slabs = en.slabs; p.S = g.S; p.sub = 4; p.ctiles = en.ctiles;
   const int bid = (int)blockIdx.x - en.block0;
-  if (TAPS == 1) wgrad1x1_body<4, true, 1>(p, bid, smem);
-  else wgrad3x3_body<true>(p, bid, smem);
+  if (TAPS == 1) wgrad1x1_body<4, true, 1, BF>(p, bid, smem);
+  else wgrad3x3_body<true, BF>(p, bid, smem);
 }
 
 // dW[e] += sum_s slabs[s][e] for a whole LIST of weight gradients in one launch: the dense-block backward queues
@@ -496,24 +578,30 @@ void wgrad1x1_tiling(int M, int C, int N, int force_sub, int& sub, int& ctiles) 
 void launch_wgrad(const WgradParams& p, hipStream_t s) {
   static bool attr = false;
   const size_t lds3 = (size_t)(2 * RK * 32 + 2 * (RK + 2) * 128 + 2 * RK) * sizeof(float);
+  const size_t lds3h = (size_t)(2 * 3 * RK * 32 + 2 * (RK + 2) * 160) * 2;
   auto lds1 = [](int sub) { return (size_t)2 * RK * (128 + 32 * sub) * sizeof(float); };
+  auto lds1h = [](int sub) { return (size_t)2 * RK * (kBfLdd + bf_lda(sub)) * 2; };     // >= the 1.5 KB fused-k table
   if (!attr) {
 #define DDL_SET_LDS(K, BYTES) DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
-    DDL_SET_LDS((wgrad1x1_kernel<1, false, 2>), lds1(1)); DDL_SET_LDS((wgrad1x1_kernel<1, true, 2>), lds1(1));
-    DDL_SET_LDS((wgrad1x1_kernel<1, false, 1>), lds1(1)); DDL_SET_LDS((wgrad1x1_kernel<1, true, 1>), lds1(1));
-    DDL_SET_LDS((wgrad1x1_kernel<3, false, 1>), lds1(3)); DDL_SET_LDS((wgrad1x1_kernel<3, true, 1>), lds1(3));
-    DDL_SET_LDS((wgrad1x1_kernel<4, false, 1>), lds1(4)); DDL_SET_LDS((wgrad1x1_kernel<4, true, 1>), lds1(4));
-    DDL_SET_LDS((wgrad3x3_kernel<false>), lds3); DDL_SET_LDS((wgrad3x3_kernel<true>), lds3);
+#define DDL_SET_LDS1(SUBV, PFV)                                                                                       \
+    DDL_SET_LDS((wgrad1x1_kernel<SUBV, false, PFV, false>), lds1(SUBV)); DDL_SET_LDS((wgrad1x1_kernel<SUBV, true, PFV, false>), lds1(SUBV)); \
+    DDL_SET_LDS((wgrad1x1_kernel<SUBV, false, PFV, true>), lds1h(SUBV)); DDL_SET_LDS((wgrad1x1_kernel<SUBV, true, PFV, true>), lds1h(SUBV))
+    DDL_SET_LDS1(1, 2); DDL_SET_LDS1(1, 1); DDL_SET_LDS1(3, 1); DDL_SET_LDS1(4, 1);
+    DDL_SET_LDS((wgrad3x3_kernel<false, false>), lds3); DDL_SET_LDS((wgrad3x3_kernel<true, false>), lds3);
+    DDL_SET_LDS((wgrad3x3_kernel<false, true>), lds3h); DDL_SET_LDS((wgrad3x3_kernel<true, true>), lds3h);
+#undef DDL_SET_LDS1
 #undef DDL_SET_LDS
     attr = true;
   }
-  const bool two = p.d.X1 != nullptr;
+  const bool two = p.d.X1 != nullptr, bf = p.bf16 != 0;
   if (p.taps == 1) {
     dim3 grid((unsigned)(p.ctiles * ((p.N + 127) / 128) * 8 * ((p.S + 7) / 8)));
-#define DDL_W1(SUBV, PFV)                                                                                    \
-    if (two) hipLaunchKernelGGL((wgrad1x1_kernel<SUBV, true, PFV>), grid, dim3(256), lds1(SUBV), s, p);        \
-    else hipLaunchKernelGGL((wgrad1x1_kernel<SUBV, false, PFV>), grid, dim3(256), lds1(SUBV), s, p)
+#define DDL_W1B(SUBV, PFV, BFV, BYTES)                                                                         \
+    if (two) hipLaunchKernelGGL((wgrad1x1_kernel<SUBV, true, PFV, BFV>), grid, dim3(256), BYTES, s, p);          \
+    else hipLaunchKernelGGL((wgrad1x1_kernel<SUBV, false, PFV, BFV>), grid, dim3(256), BYTES, s, p)
+#define DDL_W1(SUBV, PFV)                                                  \
+    if (bf) { DDL_W1B(SUBV, PFV, true, lds1h(SUBV)); } else { DDL_W1B(SUBV, PFV, false, lds1(SUBV)); }
     static const bool pf2 = [] { const char* e = ddl_knob("DDL_WGRAD_PF2"); return !(e && e[0] == '0'); }();
     switch (p.sub) {
       case 1: if (pf2) { DDL_W1(1, 2); } else { DDL_W1(1, 1); } break;
@@ -521,10 +609,16 @@ void launch_wgrad(const WgradParams& p, hipStream_t s) {
       default: DDL_W1(4, 1); break;
     }
 #undef DDL_W1
+#undef DDL_W1B
   } else {
     dim3 grid((unsigned)(3 * ((p.C + 127) / 128) * 8 * ((p.S + 7) / 8)));
-    if (two) hipLaunchKernelGGL(wgrad3x3_kernel<true>, grid, dim3(256), lds3, s, p);
-    else hipLaunchKernelGGL(wgrad3x3_kernel<false>, grid, dim3(256), lds3, s, p);
+    if (bf) {
+      if (two) hipLaunchKernelGGL((wgrad3x3_kernel<true, true>), grid, dim3(256), lds3h, s, p);
+      else hipLaunchKernelGGL((wgrad3x3_kernel<false, true>), grid, dim3(256), lds3h, s, p);
+    } else {
+      if (two) hipLaunchKernelGGL((wgrad3x3_kernel<true, false>), grid, dim3(256), lds3, s, p);
+      else hipLaunchKernelGGL((wgrad3x3_kernel<false, false>), grid, dim3(256), lds3, s, p);
+    }
   }
 }
 
@@ -538,13 +632,18 @@ void launch_wgrad_group(WgradGroupParams& g, hipStream_t s) {
   static const size_t want9 = [] { const char* e = ddl_knob("DDL_WGRAD_GROUP_LDS9"); return e ? (size_t)atol(e) : 0; }();
   size_t lds1 = (size_t)2 * RK * (128 + 128) * sizeof(float);
   size_t lds3 = (size_t)(2 * RK * 32 + 2 * (RK + 2) * 128 + 2 * RK) * sizeof(float);
+  size_t lds1h = (size_t)2 * RK * (kBfLdd + bf_lda(4)) * 2;
+  size_t lds3h = (size_t)(2 * 3 * RK * 32 + 2 * (RK + 2) * 160) * 2;
   if (want1 > lds1) lds1 = want1;
   if (want9 > lds3) lds3 = want9;
+  if (want1 > lds1h) lds1h = want1;
+  if (want9 > lds3h) lds3h = want9;
   if (!attr) {
-    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel<1>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel<9>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+#define DDL_SET_LDS(K, BYTES) DDL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
+    DDL_SET_LDS((wgrad_group_kernel<1, false>), lds1); DDL_SET_LDS((wgrad_group_kernel<9, false>), lds3);
+    DDL_SET_LDS((wgrad_group_kernel<1, true>), lds1h); DDL_SET_LDS((wgrad_group_kernel<9, true>), lds3h);
+#undef DDL_SET_LDS
     attr = true;
   }
   if (g.n <= 0) return;
@@ -555,8 +654,14 @@ void launch_wgrad_group(WgradGroupParams& g, hipStream_t s) {
     const int tiles = g.taps == 1 ? g.e[i].ctiles * ((g.N + 127) / 128) : 3 * ((g.e[i].C + 127) / 128);
     blocks += (long)tiles * s8;
   }
-  if (g.taps == 1) hipLaunchKernelGGL(wgrad_group_kernel<1>, dim3((unsigned)blocks), dim3(256), lds1, s, g);
-  else hipLaunchKernelGGL(wgrad_group_kernel<9>, dim3((unsigned)blocks), dim3(256), lds3, s, g);
+  const dim3 grid((unsigned)blocks);
+  if (g.bf16) {
+    if (g.taps == 1) hipLaunchKernelGGL((wgrad_group_kernel<1, true>), grid, dim3(256), lds1h, s, g);
+    else hipLaunchKernelGGL((wgrad_group_kernel<9, true>), grid, dim3(256), lds3h, s, g);
+  } else {
+    if (g.taps == 1) hipLaunchKernelGGL((wgrad_group_kernel<1, false>), grid, dim3(256), lds1, s, g);
+    else hipLaunchKernelGGL((wgrad_group_kernel<9, false>), grid, dim3(256), lds3, s, g);
+  }
 }
 
 // one launch for up to kMaxSlabEntries queued (slabs, S, total4, dW) reductions; block0 is filled here

@@ -180,6 +180,7 @@ class _BlockFn(torch.autograd.Function):
         done = [None] * NB
         min_rows = unit.stage.wgrad_min_rows
         bf = unit.stage.bf16
+        wbf = 1 if bf == 1 else 0         # weight gradients: bf16 MFMA in bf16 mode, fp32 MFMA otherwise (fp32x3 too)
         if fused:     # (sum g2, sum g2*h) accumulators: BN2-backward coefficients are derived by their consumers
             acc_g = torch.zeros(L, ext.STAT_REPLICAS, 2, MID, dtype=torch.int64, device=buf.device)
         # every layer's weight-gradient kernels leave partial slabs; ONE launch at the end of the block adds them
@@ -216,10 +217,10 @@ class _BlockFn(torch.autograd.Function):
                 side.wait_event(ev0)
                 with torch.cuda.stream(side):
                     ext.conv_wgrad(dy, xs, ones[:GROWTH], nq[sl], np_[sl], h[l], sc2, sh2, True, M, H, W, 9,
-                                   lay.gw2, min_rows, **wq)
+                                   lay.gw2, min_rows, **wq, prec=wbf)
             else:
                 ext.conv_wgrad(dy, xs, ones[:GROWTH], nq[sl], np_[sl], h[l], sc2, sh2, True, M, H, W, 9,
-                               lay.gw2, min_rows, **wq)
+                               lay.gw2, min_rows, **wq, prec=wbf)
             if fused:
                 kd = (None, None, None)
                 kf = dict(k_acc=acc_g[l], k_mean=bn2[l, 0], k_rstd=bn2[l, 2], k_scale=sc2, k_count=float(M))
@@ -235,14 +236,14 @@ class _BlockFn(torch.autograd.Function):
                 side.wait_event(ev1)
                 with torch.cuda.stream(side):
                     ext.conv_wgrad(g2[par], h[l], *kd, buf2d[:, :C], sc1[l], sh1[l],
-                                   True, M, H, W, 1, lay.gw1, min_rows, **kf, **wq)
+                                   True, M, H, W, 1, lay.gw1, min_rows, **kf, **wq, prec=wbf)
                     if defer == "layer":
                         wq["queue"].flush()       # the layer's 3x3 + 1x1 slabs in one launch, still cache-resident
                     done[par] = torch.cuda.Event()
                     done[par].record(side)
             else:
                 ext.conv_wgrad(g2[par], h[l], *kd, buf2d[:, :C], sc1[l], sh1[l],
-                               True, M, H, W, 1, lay.gw1, min_rows, **kf, **wq)
+                               True, M, H, W, 1, lay.gw1, min_rows, **kf, **wq, prec=wbf)
                 if defer == "layer":
                     wq["queue"].flush()
             # 1x1 data gradient: dh = k0*g2 + k1*h + k2 on the fly; epilogue: mask, dBuf += sc1*g1, sums
@@ -292,11 +293,12 @@ def _backward_grouped(ext, unit, G, main, side, d2d, buf2d, nq, np_, stats, sc1,
         n = len(group)
         ext.conv_wgrad_group(9, [d2d[:, s] for s in sls], [buf2d[:, s] for s in sls], [ones[:GROWTH]] * n,
                              [nq[s] for s in sls], [np_[s] for s in sls], [h[l] for l in group],
-                             [bn2[l, 3] for l in group], [bn2[l, 4] for l in group], [a.gw2 for a in lays], M, H, W, q)
+                             [bn2[l, 3] for l in group], [bn2[l, 4] for l in group], [a.gw2 for a in lays], M, H, W, q,
+                             1 if bf == 1 else 0)
         ext.conv_wgrad_group(1, [g2[set_, i] for i in range(n)], [h[l] for l in group], [k[set_, i, 0] for i in range(n)],
                              [k[set_, i, 1] for i in range(n)], [k[set_, i, 2] for i in range(n)],
                              [buf2d[:, :C0 + GROWTH * l] for l in group], [sc1[l] for l in group], [sh1[l] for l in group],
-                             [a.gw1 for a in lays], M, H, W, q)
+                             [a.gw1 for a in lays], M, H, W, q, 1 if bf == 1 else 0)
         q.flush()
 
     for l in range(L - 1, -1, -1):
@@ -442,7 +444,7 @@ class _TransitionFn(torch.autograd.Function):
         dy2d = dy.contiguous().view(Mp, Co)
         buf2d = buf.view(M, C)
         ext.conv_wgrad(dy2d, None, None, None, None, pooled, None, None, False, Mp, H // 2, W // 2, 1,
-                       unit.gw, unit.stage.wgrad_min_rows)
+                       unit.gw, unit.stage.wgrad_min_rows, prec=1 if unit.stage.bf16 == 1 else 0)
         dpool = torch.empty(Mp, C, **f32)
         ext.conv_gemm(dy2d, None, None, None, None, False, Mp, H // 2, W // 2, 1, False, unit.w, True,
                       dpool, False, False, None, None, None, 0, 0, unit.stage.bf16)

@@ -137,6 +137,101 @@ def test_transition_wgrad_real_shape(dev):
         _close(dW, dy.double().t() @ pooled.double(), l2=3e-6, mx=3e-5)
 
 
+# ---------------------------------------------------------------- bf16 weight gradients (`--dtype bf16`)
+def _bf16(t):
+    return t.to(torch.bfloat16).double()
+
+
+def _close_bf16(got, ref):
+    """Operands are rounded to bf16 AFTER the fp32 prologue, products accumulate in fp32.  A prologue value within one
+    fp32 ulp of a rounding boundary may round the other way in the kernel (fma contraction): judge the tensor in L2
+    and bound single outliers."""
+    got, ref = got.double(), ref.double()
+    assert float((got - ref).norm() / ref.norm().clamp_min(1e-30)) < 2e-4
+    assert float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)) < 5e-3
+
+
+@pytest.mark.parametrize("M,C,Cf", WGRAD1 + [(700, 160, 256), (37, 96, 256)])
+def test_wgrad1x1_bf16_real_shapes(dev, M, C, Cf):
+    """The 1x1 weight gradient on the bf16 matrix cores (pixel-major bf16 LDS tiles read through the transposing
+    ds_read_b64_tr_b16; every tile width SUB = 1 / 3 / 4 and a ragged last pixel step) against an fp64 GEMM of the
+    bf16-rounded operands."""
+    from ddl import ops
+    ext = ops.require_ext()
+    g2, h = _rand(M, MID, dev=dev, seed=1, scale=0.02), _rand(M, MID, dev=dev, seed=2)
+    k0, k1, k2 = (_rand(MID, dev=dev, seed=3).abs() + 0.5, _rand(MID, dev=dev, seed=4, scale=0.01),
+                  _rand(MID, dev=dev, seed=5, scale=0.01))
+    buf = _rand(M, Cf, dev=dev, seed=6)
+    sc, sh = _rand(Cf, dev=dev, seed=7).abs() + 0.5, _rand(Cf, dev=dev, seed=8)
+    dh = _bf16(k0 * g2 + k1 * h + k2)
+    a = _bf16(torch.relu(buf[:, :C] * sc[:C] + sh[:C]))
+    ref = dh.t() @ a
+    for sub in (0, 1, 3, 4):
+        dW = _rand(MID, C, dev=dev, seed=9, scale=0.1)
+        dW0 = dW.clone()
+        ext.conv_wgrad(g2, h, k0, k1, k2, buf[:, :C], sc[:C].contiguous(), sh[:C].contiguous(), True, M, 1, 1, 1, dW, 64,
+                       force_sub=sub, prec=1)
+        _close_bf16(dW.double() - dW0.double(), ref)
+
+
+@pytest.mark.parametrize("B,H,W", [(30, 56, 56), (30, 14, 14), (7, 14, 14), (6, 7, 7), (3, 5, 9)])
+def test_wgrad3x3_bf16_real_shapes(dev, B, H, W):
+    """3x3 weight gradient, bf16 MFMA: the border masks live in three per-tap copies of the dO tile."""
+    from ddl import ops
+    ext = ops.require_ext()
+    M, Cf = B * H * W, 512
+    dbuf, xbuf = _rand(M, Cf, dev=dev, seed=1, scale=0.02), _rand(M, Cf, dev=dev, seed=2)
+    sl = slice(224, 256)
+    nq, np_ = _rand(GROWTH, dev=dev, seed=3, scale=0.01), _rand(GROWTH, dev=dev, seed=4, scale=0.01)
+    ones = torch.ones(GROWTH, device=dev)
+    h = _rand(M, MID, dev=dev, seed=5)
+    sc2, sh2 = _rand(MID, dev=dev, seed=6).abs() + 0.5, _rand(MID, dev=dev, seed=7)
+    dW = torch.zeros(GROWTH, 9 * MID, device=dev)
+    ext.conv_wgrad(dbuf[:, sl], xbuf[:, sl], ones, nq, np_, h, sc2, sh2, True, M, H, W, 9, dW, 64, prec=1)
+    dy = _bf16(ones * dbuf[:, sl] + nq * xbuf[:, sl] + np_)
+    a = _bf16(torch.relu(h * sc2 + sh2))
+    _close_bf16(dW, _wgrad3x3_ref(dy, a, B, H, W))
+
+
+def test_wgrad_group_and_transition_bf16(dev):
+    """The layer-grouped launch (dense blocks 3 / 4) and the transition's plain weight gradient on the bf16 MFMA."""
+    from ddl import ops
+    ext = ops.require_ext()
+    B, H, W, C0, n = 6, 7, 7, 512, 5
+    M, Cf = B * H * W, C0 + GROWTH * n
+    dbuf, xbuf = _rand(M, Cf, dev=dev, seed=1, scale=0.02), _rand(M, Cf, dev=dev, seed=2)
+    nq, np_ = _rand(Cf, dev=dev, seed=3, scale=0.01), _rand(Cf, dev=dev, seed=4, scale=0.01)
+    ones = torch.ones(GROWTH, device=dev)
+    hs = [_rand(M, MID, dev=dev, seed=10 + i) for i in range(n)]
+    g2 = [_rand(M, MID, dev=dev, seed=20 + i, scale=0.02) for i in range(n)]
+    ks = [[_rand(MID, dev=dev, seed=30 + 3 * i + j, scale=(1.0 if j == 0 else 0.01)) for j in range(3)] for i in range(n)]
+    sc2, sh2 = [_rand(MID, dev=dev, seed=50 + i).abs() + 0.5 for i in range(n)], [_rand(MID, dev=dev, seed=60 + i) for i in range(n)]
+    sc1, sh1 = [_rand(Cf, dev=dev, seed=70 + i).abs() + 0.5 for i in range(n)], [_rand(Cf, dev=dev, seed=80 + i) for i in range(n)]
+    sls = [slice(C0 + GROWTH * i, C0 + GROWTH * (i + 1)) for i in range(n)]
+    dW2 = [torch.zeros(GROWTH, 9 * MID, device=dev) for _ in range(n)]
+    dW1 = [torch.zeros(MID, C0 + GROWTH * i, device=dev) for i in range(n)]
+    q = ext.SlabQueue()
+    ext.conv_wgrad_group(9, [dbuf[:, s] for s in sls], [xbuf[:, s] for s in sls], [ones] * n, [nq[s] for s in sls],
+                         [np_[s] for s in sls], hs, sc2, sh2, dW2, M, H, W, q, 1)
+    ext.conv_wgrad_group(1, g2, hs, [k[0] for k in ks], [k[1] for k in ks], [k[2] for k in ks],
+                         [xbuf[:, :C0 + GROWTH * i] for i in range(n)], [sc1[i][:C0 + GROWTH * i].contiguous() for i in range(n)],
+                         [sh1[i][:C0 + GROWTH * i].contiguous() for i in range(n)], dW1, M, H, W, q, 1)
+    q.flush()
+    for i in range(n):
+        dy = _bf16(ones * dbuf[:, sls[i]] + nq[sls[i]] * xbuf[:, sls[i]] + np_[sls[i]])
+        a = _bf16(torch.relu(hs[i] * sc2[i] + sh2[i]))
+        _close_bf16(dW2[i], _wgrad3x3_ref(dy, a, B, H, W))
+        C = C0 + GROWTH * i
+        dh = _bf16(ks[i][0] * g2[i] + ks[i][1] * hs[i] + ks[i][2])
+        a1 = _bf16(torch.relu(xbuf[:, :C] * sc1[i][:C] + sh1[i][:C]))
+        _close_bf16(dW1[i], dh.t() @ a1)
+    for Mp, C, Co in ((23520, 256, 128), (1470, 1024, 512)):
+        dy, pooled = _rand(Mp, Co, dev=dev, seed=1, scale=0.02), _rand(Mp, C, dev=dev, seed=2)
+        dW = torch.zeros(Co, C, device=dev)
+        ext.conv_wgrad(dy, None, None, None, None, pooled, None, None, False, Mp, 1, 1, 1, dW, 64, prec=1)
+        _close_bf16(dW, _bf16(dy).t() @ _bf16(pooled))
+
+
 # ------------------------------------------------------------------------------------------- rows_op
 @pytest.mark.parametrize("M,C,Cf", [(94080, 64, 256), (1470, 512, 1024), (5880, 256, 1024)])
 def test_rows_op_copy_stats(dev, M, C, Cf):
