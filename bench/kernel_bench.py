@@ -21,6 +21,7 @@ ap.add_argument("--prec", type=int, default=None, help="matrix-core path of the 
 ap.add_argument("--min-rows", type=int, default=64, help="wgrad: minimum pixel rows per workgroup")
 ap.add_argument("--sub", type=int, default=0, help="wgrad 1x1: force the sub-tile count (1, 3, 4) of the channel tiles")
 ap.add_argument("--defer", action="store_true", help="wgrad: queue the slab reductions (timed: the slab kernels alone)")
+ap.add_argument("--dump", default="", help="--probe: directory for per-workgroup (start, end, placement) CSVs")
 ap.add_argument("--probe", action="store_true", help="phase timestamps of the first / last workgroup (needs a "
                                                    "DDL_BUILD_DEFINES=-DDDL_PHASE_PROBE build of the extension)")
 ap.add_argument("--sweep", action="store_true", help="time every conv_gemm tile config per case")
@@ -148,12 +149,47 @@ PHASES = ["entry", "loads issued + tables", "first slab in LDS", "K loop", "K-sp
 
 
 def probe(name, fn):
-    dbg = torch.zeros(32, dtype=torch.int64, device=dev)
+    dbg = torch.zeros(32 + 3 * 2048, dtype=torch.int64, device=dev)
     ext.set_phase_probe(dbg)
     fn()
     torch.cuda.synchronize()
     ext.set_phase_probe(None)
     t = dbg.cpu().tolist()
+    if "wgrad1x1" in name:      # per-phase sums over the pixel steps (conv_wgrad.hip, probe builds)
+        names = ["prologue", "load issue", "LDS reads + MFMA issue", "exposed load wait", "prologue math + LDS writes", "barrier"]
+        for label, off in (("WG 0", 0), ("WG 264", 16)):
+            v = t[off:off + 10]
+            if v[6] == 0:
+                continue
+            print(f"    {label}: {v[6]} steps, {(v[8] - v[7]) / 100:.2f} us at {v[9] / max(1, v[8] - v[7]) / 10:.2f} GHz shader clock | "
+                  + " | ".join(f"{n} {x / 100:.2f}" for n, x in zip(names, v[:6])), flush=True)
+        wg = [(t[32 + 3 * i], t[33 + 3 * i], t[34 + 3 * i]) for i in range(2048) if t[32 + 3 * i]]
+        if wg:
+            t0 = min(w[0] for w in wg)
+            if a.dump:
+                with open(f"{a.dump}/{name}.csv", "w") as f:
+                    f.write("bid,start_us,end_us,xcc,hw_id\n")
+                    for i in range(2048):
+                        if t[32 + 3 * i]:
+                            f.write(f"{i},{(t[32 + 3 * i] - t0) / 100:.2f},{(t[33 + 3 * i] - t0) / 100:.2f},"
+                                    f"{(t[34 + 3 * i] >> 32) & 0xf},{t[34 + 3 * i] & 0xffffffff}\n")
+            starts = sorted((w[0] - t0) / 100 for w in wg)
+            ends = sorted((w[1] - t0) / 100 for w in wg)
+            life = sorted((w[1] - w[0]) / 100 for w in wg)
+            q = lambda v, f: v[min(len(v) - 1, int(f * len(v)))]
+            print(f"    {len(wg)} workgroups: start p50 {q(starts, .5):.1f} p90 {q(starts, .9):.1f} max {starts[-1]:.1f} us | "
+                  f"end p10 {q(ends, .1):.1f} p50 {q(ends, .5):.1f} max {ends[-1]:.1f} us | life p10 {q(life, .1):.1f} p50 {q(life, .5):.1f} "
+                  f"p90 {q(life, .9):.1f} max {life[-1]:.1f} us", flush=True)
+            import collections
+            per_cu = collections.Counter()
+            for s0, e0, idw in wg:
+                xcc, hw = idw >> 32, idw & 0xffffffff
+                per_cu[(xcc & 0xf, (hw >> 8) & 0xff)] += 1       # (XCC, SE / SH / CU bits of HW_ID)
+            hist = collections.Counter(per_cu.values())
+            print(f"    placement: {len(per_cu)} distinct (XCC, SE, CU); workgroups per CU histogram {dict(sorted(hist.items()))}", flush=True)
+            late = [w for w in wg if (w[0] - t0) / 100 > 5.0]
+            print(f"    {len(late)} workgroups start more than 5 us after the first", flush=True)
+        return
     for label, off in (("first WG", 0), ("last WG", 16)):
         v = t[off:off + 9]
         if v[0] == 0:

@@ -25,7 +25,7 @@ for r in sel:
         n = "conv_gemm<%s,%s,ks%s,nbuf%s,pf%s,%s>" % (m.group(1), m.group(2), m.group(5), m.group(6), m.group(7),
                                                      ("fwd", "tdgrad", "dgrad3x3", "dgrad1x1")[int(m.group(8))])
     else:
-        m = re.search(r"(wgrad_group_kernel<\d>|wgrad\dx\d_kernel|slab_reduce_multi_kernel|slab_reduce_kernel|bn_prep_kernel|bn_bwd_prep_kernel|rows_op_kernel|"
+        m = re.search(r"(wgrad_group_kernel<\d(?:, \w+)?>|wgrad\dx\d_kernel|slab_reduce_multi_kernel|slab_reduce_kernel|bn_prep_kernel|bn_bwd_prep_kernel|rows_op_kernel|"
                       r"adam_flat_kernel|ce_fwd_bwd_kernel|normalize_u8_kernel|bnrelu_gap_fwd_kernel|stem_\w+_kernel|"
                       r"linear_\w+_kernel|adam_inc_step_kernel)", n)
         n = m.group(1) if m else re.sub(r"\(.*", "", n)[:60]

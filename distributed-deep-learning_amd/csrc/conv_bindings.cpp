@@ -71,10 +71,12 @@ float* fvec(const at::Tensor& t, int64_t n, const char* name) {
 
 #ifdef DDL_PHASE_PROBE
 long long* g_phase_probe = nullptr;      // bench/phase_probe.py: [2][16] int64 device buffer, or null
+int64_t g_phase_probe_n = 0;             // its length: the weight-gradient probe also logs (start, end) of 2048 workgroups
 void set_phase_probe(const OptT& t) {
-  if (!t.has_value()) { g_phase_probe = nullptr; return; }
+  if (!t.has_value()) { g_phase_probe = nullptr; g_phase_probe_n = 0; return; }
   TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kLong && t->is_contiguous() && t->numel() >= 32, "probe: int64[32]");
   g_phase_probe = reinterpret_cast<long long*>(t->data_ptr<int64_t>());
+  g_phase_probe_n = t->numel();
 }
 #define DDL_SET_PROBE(p) (p).dbg = g_phase_probe
 #else
@@ -347,6 +349,12 @@ void conv_wgrad(const at::Tensor& d0, const OptT& d1, const OptT& ds0, const Opt
   p.S = (int)((M + p.rows_per_wg - 1) / p.rows_per_wg);
   auto slabs = at::empty({p.S, N, taps * C}, d0.options());
   p.slabs = slabs.data_ptr<float>();
+  static const int wprio = [] { const char* e = ddl_knob("DDL_WGRAD_PRIO"); return e ? atoi(e) : 0; }();
+  p.prio = wprio;
+  DDL_SET_PROBE(p);
+#ifdef DDL_PHASE_PROBE
+  if (g_phase_probe_n < 32 + 3 * 2048) p.dbg = nullptr;
+#endif
   ddl::launch_wgrad(p, cur_stream());
   const int64_t total4 = N * taps * C / 4;
   if (queue != nullptr) {

@@ -25,6 +25,7 @@
 // prologue, and stay pixel-major - no transposing store, no second layout.  Row strides are 64 B (mod 256 B) so the
 // four rows of a block fall into disjoint bank groups (checked on the device: bench/r3/tr_read_check.hip).
 #include <cstdlib>
+#include <type_traits>
 
 #include "conv_params.h"
 #include "ddl_kernels.h"
@@ -122,7 +123,12 @@ constexpr int kBfLdd = 160;                                                // ..
 __device__ __forceinline__ bool xcd_group(int id, int T, int S, int& t, int& chunk) {
   const int lo = id & 7, rest = id >> 3;
   const int hi = rest / T;
+  // An XCD deals its workgroups round-robin over its 32 CUs: the k-th and the (k+32)-th of an XCD share a CU (probe:
+  // 234 of 234 pairs, profiles/r3/wgrad_probe.md).  Tiles of different cost (a last channel tile with fewer live
+  // sub-tiles) would pair up like with like - (96, 96)-column pairs ran 52 us, (64, 64) pairs 42 us - so every pass
+  // over the CUs rotates the tile order by one: a CU then holds one of each.
   t = rest - hi * T;
+  if (32 % T == 0) t = (t + ((hi * T) >> 5)) % T;       // otherwise k and k + 32 differ mod T already
   chunk = hi * 8 + lo;
   return chunk < S;
 }
@@ -150,7 +156,16 @@ __device__ __forceinline__ void wgrad1x1_body(const WgradParams& p, const int bi
   const int ctiles = p.ctiles, ntiles = (p.N + 127) / 128;
   int t_idx, chunk;
   if (!xcd_group(bid, ctiles * ntiles, p.S, t_idx, chunk)) return;     // grid padded to 8 chunks
-  const int c0 = (t_idx % ctiles) * TC, n0 = (t_idx / ctiles) * 128;
+  if (p.prio) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    if (p.prio == 1 && (hw & 1)) __builtin_amdgcn_s_setprio(3);
+  }
+  // the C / 32 sub-tiles are dealt evenly over the channel tiles (10 over 3 tiles: 3 + 3 + 4, not 4 + 4 + 2)
+  const int nsub = (p.C + 31) / 32, ct = t_idx % ctiles;
+  const int sub0 = ct * nsub / ctiles;
+  const int nlive = (ct + 1) * nsub / ctiles - sub0;        // live sub-tiles of this tile: 1 ... SUB (host: ctiles * SUB >= nsub)
+  const int c0 = sub0 * 32, n0 = (t_idx / ctiles) * 128;
   const int mb = chunk * p.rows_per_wg;
   int me = mb + p.rows_per_wg;
   if (me > p.M) me = p.M;
@@ -188,7 +203,7 @@ __device__ __forceinline__ void wgrad1x1_body(const WgradParams& p, const int bi
     const int m = mrow + ar;
 #pragma unroll
     for (int j = 0; j < SUB; ++j)
-      R.a[j] = pix_fetch<false>(da, m, c0 + 32 * j + aq, m < me && c0 + 32 * j + aq < p.C);
+      R.a[j] = pix_fetch<false>(da, m, c0 + 32 * j + aq, m < me && j < nlive && c0 + 32 * j + aq < p.C);
   };
   auto store_step = [&](int buf, const Raw& R) {
     if constexpr (BF) {
@@ -215,84 +230,137 @@ __device__ __forceinline__ void wgrad1x1_body(const WgradParams& p, const int bi
   for (int j = 0; j < SUB; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  // sub-tiles beyond C (the last channel tile of an unbalanced split): wave-uniform skip
-  bool live[SUB];
-#pragma unroll
-  for (int j = 0; j < SUB; ++j) live[j] = c0 + 32 * j < p.C;
+  // Sub-tiles beyond C (the last channel tile of an uneven split) are skipped.  The number of live sub-tiles NL is a
+  // property of the WORKGROUP, so the whole pixel loop is instantiated per NL (`run` below) instead of guarding every
+  // MFMA: a wave-uniform `if (live[j])` compiles to a branch around each MFMA, every MFMA sits in its own basic block,
+  // and hipcc can neither hoist the operands' LDS reads over the preceding MFMAs nor batch them.  With one or two
+  // waves per SIMD nobody else covers that latency: the MFMA + LDS-read part of a step ran at 65 % (one resident
+  // workgroup) / 79 % (two) of the matrix pipe's pace with the staging knocked out (profiles/r3/wgrad_probe.md).
 
   // transposing-read block address of this lane: row 8*lh + q, columns 16*(half of li) + 4p
   const int trow = 8 * lh + ((lane & 15) >> 2), tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, auto nl_tag) {
+    constexpr int NL = decltype(nl_tag)::value;
     if constexpr (BF) {
 #pragma unroll
       for (int ks = 0; ks < RK / 16; ++ks) {
         const bf16x8 d = lds_tr8(Dh + buf * RK * LDD + (16 * ks + trow) * LDD + wid * 32 + tcol, LDD);
-        bf16x8 av[SUB];
+        bf16x8 av[NL];
 #pragma unroll
-        for (int j = 0; j < SUB; ++j) av[j] = lds_tr8(Ah + buf * RK * LDA + (16 * ks + trow) * LDA + 32 * j + tcol, LDA);
+        for (int j = 0; j < NL; ++j) av[j] = lds_tr8(Ah + buf * RK * LDA + (16 * ks + trow) * LDA + 32 * j + tcol, LDA);
 #pragma unroll
-        for (int j = 0; j < SUB; ++j)
-          if (live[j]) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d, av[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < NL; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d, av[j], acc[j], 0, 0, 0);
       }
       return;
     }
-    const float* Db = Ds + buf * RK * 128 + wid * 32 + li;
-    const float* Ab = As + buf * RK * TC + li;
+    // one basic block of 16 k-pairs, software-pipelined: the operands of pair s + PD are read from LDS in front of
+    // the MFMAs of pair s (PD pairs = ~128-256 cycles of matrix-pipe time ahead; hipcc left to itself sinks the reads
+    // back behind the MFMAs, hence the scheduling barriers)
+    constexpr int PD = NL >= 3 ? 1 : (NL == 2 ? 2 : 3);
+    const float* Db = Ds + buf * RK * 128 + wid * 32 + li + lh * 128;
+    const float* Ab = As + buf * RK * TC + li + lh * TC;
+    float dq[PD + 1], aq[PD + 1][NL];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {     // operands of 8 k-pairs at a time: the MFMAs then issue back to back
-      float d[RK / 4], av[RK / 4][SUB];
+    for (int g = 0; g < PD; ++g) {
+      dq[g] = Db[2 * g * 128];
 #pragma unroll
-      for (int s = 0; s < RK / 4; ++s) {
-        const int r = 2 * (half * (RK / 4) + s) + lh;
-        d[s] = Db[r * 128];
+      for (int j = 0; j < NL; ++j) aq[g][j] = Ab[2 * g * TC + 32 * j];
+    }
 #pragma unroll
-        for (int j = 0; j < SUB; ++j) av[s][j] = Ab[r * TC + 32 * j];
+    for (int s = 0; s < RK / 2; ++s) {
+      if (s + PD < RK / 2) {
+        dq[(s + PD) % (PD + 1)] = Db[2 * (s + PD) * 128];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) aq[(s + PD) % (PD + 1)][j] = Ab[2 * (s + PD) * TC + 32 * j];
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < RK / 4; ++s)
-#pragma unroll
-        for (int j = 0; j < SUB; ++j)
-          if (live[j]) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[s], av[s][j], acc[j], 0, 0, 0);
+      for (int j = 0; j < NL; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(dq[s % (PD + 1)], aq[s % (PD + 1)][j], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  if (PF == 1) {
-    Raw R;
-    if (steps > 0) {
-      load_step(0, R);
-      store_step(0, R);
-    }
-    __syncthreads();
+  // probe builds (bench/kernel_bench.py --probe): where a workgroup's time goes, summed over its pixel steps
+#ifdef DDL_PHASE_PROBE
+  long long tp[6] = {0, 0, 0, 0, 0, 0};
+  long long tl = (long long)wall_clock64();
+  const long long tstart = tl, cstart = (long long)clock64();      // shader-clock cycles beside the 100 MHz wall clock
+#define DDL_WPROBE(i) do { const long long n_ = (long long)wall_clock64(); tp[i] += n_ - tl; tl = n_; } while (0)
+#define DDL_WPROBE_VMWAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define DDL_WPROBE(i) do {} while (0)
+#define DDL_WPROBE_VMWAIT() do {} while (0)
+#endif
+  auto run = [&](auto nl) {
+    if (PF == 1) {
+      Raw R;
+      if (steps > 0) {
+        load_step(0, R);
+        store_step(0, R);
+      }
+      __syncthreads();
+      DDL_WPROBE(0);                                    // prologue: tables + first step staged
 #pragma unroll 1
-    for (int st = 0; st < steps; ++st) {
-      const int buf = st & 1;
-      if (st + 1 < steps) load_step(st + 1, R);
-      compute(buf);
-      if (st + 1 < steps) store_step(buf ^ 1, R);
+      for (int st = 0; st < steps; ++st) {
+        const int buf = st & 1;
+#ifdef DDL_PHASE_PROBE      // knock-outs (p.prio 2: no staging in the loop, 3: no MFMAs) - timing experiments, wrong results
+        const bool ko_stage = p.prio == 2, ko_mfma = p.prio == 3;
+#else
+        constexpr bool ko_stage = false, ko_mfma = false;
+#endif
+        if (st + 1 < steps && !ko_stage) load_step(st + 1, R);
+        DDL_WPROBE(1);                                  // loads issued
+        if (!ko_mfma) compute(buf, nl);
+        DDL_WPROBE(2);                                  // LDS reads + MFMAs issued
+        DDL_WPROBE_VMWAIT();
+        DDL_WPROBE(3);                                  // exposed wait for the next step's loads
+        if (st + 1 < steps && !ko_stage) store_step(buf ^ 1, R);
+        DDL_WPROBE(4);                                  // prologue arithmetic + LDS writes
+        __syncthreads();
+        DDL_WPROBE(5);                                  // barrier
+      }
+    } else {
+      // prefetch distance 2: step st in LDS, st+1 in registers, st+2 being loaded.  A 32-column tile has only
+      // 16 MFMAs (1024 cycles) per wave and step - far less than one trip to HBM / L2 under load, so with a
+      // single step in flight the loop runs at memory latency; two steps give every load two compute phases.
+      Raw R0, R1;
+      if (steps > 0) load_step(0, R0);
+      if (steps > 1) load_step(1, R1);
+      if (steps > 0) store_step(0, R0);
       __syncthreads();
-    }
-  } else {
-    // prefetch distance 2: step st in LDS, st+1 in registers, st+2 being loaded.  A 32-column tile has only
-    // 16 MFMAs (1024 cycles) per wave and step - far less than one trip to HBM / L2 under load, so with a
-    // single step in flight the loop runs at memory latency; two steps give every load two compute phases.
-    Raw R0, R1;
-    if (steps > 0) load_step(0, R0);
-    if (steps > 1) load_step(1, R1);
-    if (steps > 0) store_step(0, R0);
-    __syncthreads();
 #pragma unroll 1
-    for (int st = 0; st < steps; st += 2) {
-      if (st + 2 < steps) load_step(st + 2, R0);
-      compute(0);
-      if (st + 1 < steps) store_step(1, R1);
-      __syncthreads();
-      if (st + 1 >= steps) break;
-      if (st + 3 < steps) load_step(st + 3, R1);
-      compute(1);
-      if (st + 2 < steps) store_step(0, R0);
-      __syncthreads();
+      for (int st = 0; st < steps; st += 2) {
+        if (st + 2 < steps) load_step(st + 2, R0);
+        compute(0, nl);
+        if (st + 1 < steps) store_step(1, R1);
+        __syncthreads();
+        if (st + 1 >= steps) break;
+        if (st + 3 < steps) load_step(st + 3, R1);
+        compute(1, nl);
+        if (st + 2 < steps) store_step(0, R0);
+        __syncthreads();
+      }
     }
+  };
+  if (nlive >= SUB) run(std::integral_constant<int, SUB>{});
+  else if (SUB > 2 && nlive == SUB - 1) run(std::integral_constant<int, (SUB > 2 ? SUB - 1 : 1)>{});
+  else if (SUB > 3 && nlive == SUB - 2) run(std::integral_constant<int, (SUB > 3 ? SUB - 2 : 1)>{});
+  else run(std::integral_constant<int, 1>{});
+#ifdef DDL_PHASE_PROBE
+  if (p.dbg != nullptr && tid == 0 && (bid == 0 || bid == 264)) {
+    long long* o = p.dbg + (bid == 0 ? 0 : 16);
+    for (int i = 0; i < 6; ++i) o[i] = tp[i];
+    o[6] = steps; o[7] = tstart; o[8] = tl; o[9] = (long long)clock64() - cstart;
   }
+  if (p.dbg != nullptr && tid == 0 && bid < 2048) {      // (start, end, XCC / CU id) of every workgroup
+    p.dbg[32 + 3 * bid] = tstart; p.dbg[33 + 3 * bid] = (long long)wall_clock64();
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    p.dbg[34 + 3 * bid] = ((long long)xcc << 32) | hw;
+  }
+#endif
   // slab write: slabs[chunk][n][c]
   float* slab = p.slabs + (long)chunk * p.N * p.C;
 #pragma unroll
@@ -301,7 +369,7 @@ __device__ __forceinline__ void wgrad1x1_body(const WgradParams& p, const int bi
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = n0 + wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (n < p.N && c < p.C) slab[(long)n * p.C + c] = acc[j][r];
+      if (j < nlive && n < p.N && c < p.C) slab[(long)n * p.C + c] = acc[j][r];
     }
   }
 }
@@ -428,20 +496,34 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradParams& p, const int bi
         for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d[t], a[t], acc[t], 0, 0, 0);
       }
     } else {
-      const float* Db = Ds + buf * RK * 32 + li;
-      const float* Ab = As + buf * AR * 128 + wid * 32 + li;
-      const int* Fb = Fl + buf * RK;
+      // software-pipelined like the 1x1 kernel: the operands of k-pair s+1 are read in front of the MFMAs of pair s
+      // (left alone hipcc reads each operand right in front of its MFMA behind s_waitcnt lgkmcnt(0)); activation row
+      // r + 2 of pair s is row r of pair s + 1, so a pair costs four LDS reads: dO, mask, two activation rows
+      const float* Db = Ds + buf * RK * 32 + li + lh * 32;
+      const float* Ab = As + buf * AR * 128 + wid * 32 + li + lh * 128;
+      const int* Fb = Fl + buf * RK + lh;
+      float dq[2], aq[2][3];
+      int fq[2];
+      dq[0] = Db[0]; fq[0] = Fb[0];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) aq[0][t] = Ab[t * 128];
 #pragma unroll
       for (int s = 0; s < RK / 2; ++s) {
-        const int r = 2 * s + lh;
-        const float d = Db[r * 32];
-        const int fl = Fb[r];
+        const int c = s & 1, n = c ^ 1;
+        if (s + 1 < RK / 2) {
+          dq[n] = Db[2 * (s + 1) * 32];
+          fq[n] = Fb[2 * (s + 1)];
+          aq[n][0] = aq[c][2];
+          aq[n][1] = Ab[(2 * (s + 1) + 1) * 128];
+          aq[n][2] = Ab[(2 * (s + 1) + 2) * 128];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-          float a = Ab[(r + t) * 128];
-          a = ((fl >> t) & 1) ? a : 0.f;
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(d, a, acc[t], 0, 0, 0);
+          const float a = ((fq[c] >> t) & 1) ? aq[c][t] : 0.f;
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(dq[c], a, acc[t], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (st + 1 < steps) store_step(buf ^ 1);
@@ -497,6 +579,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_group_kernel(const WgradGroupPar
   p.a.bytes1 = 0;
   p.M = g.M; p.C = en.C; p.N = g.N; p.H = g.H; p.W = g.W; p.taps = TAPS;
   p.rows_per_wg = g.rows_per_wg; p.slabs = en.slabs; p.S = g.S; p.sub = 4; p.ctiles = en.ctiles;
+  p.bf16 = g.bf16; p.prio = 0;
+#ifdef DDL_PHASE_PROBE
+  p.dbg = nullptr;
+#endif
   const int bid = (int)blockIdx.x - en.block0;
   if (TAPS == 1) wgrad1x1_body<4, true, 1, BF>(p, bid, smem);
   else wgrad3x3_body<true, BF>(p, bid, smem);

@@ -180,7 +180,7 @@ class _BlockFn(torch.autograd.Function):
         done = [None] * NB
         min_rows = unit.stage.wgrad_min_rows
         bf = unit.stage.bf16
-        wbf = 1 if bf == 1 else 0         # weight gradients: bf16 MFMA in bf16 mode, fp32 MFMA otherwise (fp32x3 too)
+        wbf = unit.stage.wgrad_prec       # weight gradients: bf16 MFMA in bf16 mode, fp32 MFMA otherwise (fp32x3 too)
         if fused:     # (sum g2, sum g2*h) accumulators: BN2-backward coefficients are derived by their consumers
             acc_g = torch.zeros(L, ext.STAT_REPLICAS, 2, MID, dtype=torch.int64, device=buf.device)
         # every layer's weight-gradient kernels leave partial slabs; ONE launch at the end of the block adds them
@@ -294,11 +294,11 @@ def _backward_grouped(ext, unit, G, main, side, d2d, buf2d, nq, np_, stats, sc1,
         ext.conv_wgrad_group(9, [d2d[:, s] for s in sls], [buf2d[:, s] for s in sls], [ones[:GROWTH]] * n,
                              [nq[s] for s in sls], [np_[s] for s in sls], [h[l] for l in group],
                              [bn2[l, 3] for l in group], [bn2[l, 4] for l in group], [a.gw2 for a in lays], M, H, W, q,
-                             1 if bf == 1 else 0)
+                             unit.stage.wgrad_prec)
         ext.conv_wgrad_group(1, [g2[set_, i] for i in range(n)], [h[l] for l in group], [k[set_, i, 0] for i in range(n)],
                              [k[set_, i, 1] for i in range(n)], [k[set_, i, 2] for i in range(n)],
                              [buf2d[:, :C0 + GROWTH * l] for l in group], [sc1[l] for l in group], [sh1[l] for l in group],
-                             [a.gw1 for a in lays], M, H, W, q, 1 if bf == 1 else 0)
+                             [a.gw1 for a in lays], M, H, W, q, unit.stage.wgrad_prec)
         q.flush()
 
     for l in range(L - 1, -1, -1):
@@ -444,7 +444,7 @@ class _TransitionFn(torch.autograd.Function):
         dy2d = dy.contiguous().view(Mp, Co)
         buf2d = buf.view(M, C)
         ext.conv_wgrad(dy2d, None, None, None, None, pooled, None, None, False, Mp, H // 2, W // 2, 1,
-                       unit.gw, unit.stage.wgrad_min_rows, prec=1 if unit.stage.bf16 == 1 else 0)
+                       unit.gw, unit.stage.wgrad_min_rows, prec=unit.stage.wgrad_prec)
         dpool = torch.empty(Mp, C, **f32)
         ext.conv_gemm(dy2d, None, None, None, None, False, Mp, H // 2, W // 2, 1, False, unit.w, True,
                       dpool, False, False, None, None, None, 0, 0, unit.stage.bf16)
@@ -619,6 +619,9 @@ class NativeDenseNetStage(nn.Module):
         # kernels are staging-bound, so it only wins on the block-1 1x1 forward.
         # `bf16` is the matrix-core path selector handed to the kernels: 0 fp32 MFMA, 1 bf16, 3 split.
         self.bf16 = {"fp32": 0, "bf16": 1, "fp32x3": 3}[dtype]
+        # weight gradients: bf16 MFMA (transposing LDS reads, csrc/conv_wgrad.hip) in bf16 mode only; DDL_WGRAD_PREC is the
+        # A/B switch of the experiment "how much of the fp32 step do the weight gradients cost" (profiles/r3/bf16_wgrad)
+        self.wgrad_prec = int(knob("DDL_WGRAD_PREC", "1" if self.bf16 == 1 else "0"))
         # Fused BN statistics (csrc/conv_params.h FusedBn / FusedK): forward on by default (2 bn_prep launches
         # per dense layer leave the single-stream forward chain: 10.41 -> 9.92 ms/step at batch 30).  The
         # backward variant (BN2 coefficients derived inside the 1x1 dgrad / wgrad) removes 58 more launches
