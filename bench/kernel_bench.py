@@ -155,7 +155,7 @@ def probe(name, fn):
     torch.cuda.synchronize()
     ext.set_phase_probe(None)
     t = dbg.cpu().tolist()
-    if "wgrad1x1" in name:      # per-phase sums over the pixel steps (conv_wgrad.hip, probe builds)
+    if "wgrad" in name:      # per-phase sums over the pixel steps (conv_wgrad.hip, probe builds)
         names = ["prologue", "load issue", "LDS reads + MFMA issue", "exposed load wait", "prologue math + LDS writes", "barrier"]
         for label, off in (("WG 0", 0), ("WG 264", 16)):
             v = t[off:off + 10]

@@ -124,7 +124,7 @@ __device__ __forceinline__ bool xcd_group(int id, int T, int S, int& t, int& chu
   const int lo = id & 7, rest = id >> 3;
   const int hi = rest / T;
   // An XCD deals its workgroups round-robin over its 32 CUs: the k-th and the (k+32)-th of an XCD share a CU (probe:
-  // 234 of 234 pairs, profiles/r3/wgrad_probe.md).  Tiles of different cost (a last channel tile with fewer live
+  // 234 of 234 pairs, profiles/r3/wgrad_probe/README.md).  Tiles of different cost (a last channel tile with fewer live
   // sub-tiles) would pair up like with like - (96, 96)-column pairs ran 52 us, (64, 64) pairs 42 us - so every pass
   // over the CUs rotates the tile order by one: a CU then holds one of each.
   t = rest - hi * T;
@@ -235,7 +235,7 @@ __device__ __forceinline__ void wgrad1x1_body(const WgradParams& p, const int bi
   // MFMA: a wave-uniform `if (live[j])` compiles to a branch around each MFMA, every MFMA sits in its own basic block,
   // and hipcc can neither hoist the operands' LDS reads over the preceding MFMAs nor batch them.  With one or two
   // waves per SIMD nobody else covers that latency: the MFMA + LDS-read part of a step ran at 65 % (one resident
-  // workgroup) / 79 % (two) of the matrix pipe's pace with the staging knocked out (profiles/r3/wgrad_probe.md).
+  // workgroup) / 79 % (two) of the matrix pipe's pace with the staging knocked out (profiles/r3/wgrad_probe/README.md).
 
   // transposing-read block address of this lane: row 8*lh + q, columns 16*(half of li) + 4p
   const int trow = 8 * lh + ((lane & 15) >> 2), tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
@@ -400,6 +400,9 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradParams& p, const int bi
   const int ctiles = (p.C + 127) / 128;
   int t_idx, chunk;
   if (!xcd_group(bid, 3 * ctiles, p.S, t_idx, chunk)) return;          // grid padded to 8 chunks
+#ifdef DDL_PHASE_PROBE
+  const long long tstart3 = (long long)wall_clock64(), cstart3 = (long long)clock64();
+#endif
   const int dy = t_idx % 3 - 1;
   const int cbase = (t_idx / 3) * 128;
   const int HW = p.H * p.W;
@@ -481,8 +484,14 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradParams& p, const int bi
   __syncthreads();
   for (int st = 0; st < steps; ++st) {
     const int buf = st & 1;
-    if (st + 1 < steps) load_step(st + 1);
-    if constexpr (BF) {
+#ifdef DDL_PHASE_PROBE      // knock-outs (p.prio 2: no staging in the loop, 3: no MFMAs) - timing experiments, wrong results
+    const bool ko_stage = p.prio == 2, ko_mfma = p.prio == 3;
+#else
+    constexpr bool ko_stage = false, ko_mfma = false;
+#endif
+    if (st + 1 < steps && !ko_stage) load_step(st + 1);
+    if (ko_mfma) {
+    } else if constexpr (BF) {
       const int trow = 8 * lh + ((lane & 15) >> 2), tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 #pragma unroll
       for (int ks = 0; ks < RK / 16; ++ks) {
@@ -526,9 +535,19 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradParams& p, const int bi
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (st + 1 < steps) store_step(buf ^ 1);
+    if (st + 1 < steps && !ko_stage) store_step(buf ^ 1);
     __syncthreads();
   }
+#ifdef DDL_PHASE_PROBE
+  if (p.dbg != nullptr && tid == 0 && bid < 2048) {      // (start, end, XCC / CU id) of every workgroup
+    p.dbg[32 + 3 * bid] = tstart3; p.dbg[33 + 3 * bid] = (long long)wall_clock64();
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    p.dbg[34 + 3 * bid] = ((long long)xcc << 32) | hw;
+    if (bid == 0) { p.dbg[6] = steps; p.dbg[7] = tstart3; p.dbg[8] = p.dbg[33]; p.dbg[9] = (long long)clock64() - cstart3; }
+  }
+#endif
   const int KC = 9 * p.C;
   float* slab = p.slabs + (long)chunk * p.N * KC;
 #pragma unroll
