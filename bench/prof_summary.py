@@ -26,7 +26,7 @@ for r in sel:
                                                      ("fwd", "tdgrad", "dgrad3x3", "dgrad1x1")[int(m.group(8))])
     else:
         m = re.search(r"(wgrad_group_kernel<\d(?:, \w+)?>|wgrad\dx\d_kernel|slab_reduce_multi_kernel|slab_reduce_kernel|bn_prep_kernel|bn_bwd_prep_kernel|rows_op_kernel|"
-                      r"adam_flat_kernel|ce_fwd_bwd_kernel|normalize_u8_kernel|bnrelu_gap_fwd_kernel|stem_\w+_kernel|"
+                      r"adam_flat_kernel|ce_fwd_bwd_kernel|conv3x3_small_kernel|conv3x3_halo_kernel|stem_pack_kernel|normalize_u8_kernel|bnrelu_gap_fwd_kernel|stem_\w+_kernel|"
                       r"linear_\w+_kernel|adam_inc_step_kernel)", n)
         n = m.group(1) if m else re.sub(r"\(.*", "", n)[:60]
     if detail:
