@@ -349,11 +349,11 @@ void conv_wgrad(const at::Tensor& d0, const OptT& d1, const OptT& ds0, const Opt
   p.S = (int)((M + p.rows_per_wg - 1) / p.rows_per_wg);
   auto slabs = at::empty({p.S, N, taps * C}, d0.options());
   p.slabs = slabs.data_ptr<float>();
-  static const int wprio = [] { const char* e = ddl_knob("DDL_WGRAD_PRIO"); return e ? atoi(e) : 0; }();
-  p.prio = wprio;
   DDL_SET_PROBE(p);
 #ifdef DDL_PHASE_PROBE
   if (g_phase_probe_n < 32 + 3 * 2048) p.dbg = nullptr;
+  static const int wko = [] { const char* e = ddl_knob("DDL_WGRAD_KO"); return e ? atoi(e) : 0; }();
+  p.ko = wko;
 #endif
   ddl::launch_wgrad(p, cur_stream());
   const int64_t total4 = N * taps * C / 4;

@@ -155,8 +155,8 @@ struct WgradParams {
   int sub;            // 1x1: 32-column sub-tiles per workgroup tile (1..4) and the number of channel tiles
   int ctiles;
   int bf16;           // 1: operands rounded to bf16 at the LDS write, v_mfma_f32_32x32x16_bf16 via transposing LDS reads
-  int prio;           // 1: waves in odd hardware slots raise their issue priority (breaks the lock-step of co-resident workgroups)
 #ifdef DDL_PHASE_PROBE
+  int ko;             // timing knock-outs of the pixel loop (2: no staging, 3: no MFMAs; wrong results) - probe builds only
   long long* dbg;     // [2][16]: per-phase time (100 MHz ticks) summed over the pixel steps of the first / a middle workgroup
 #endif
 };

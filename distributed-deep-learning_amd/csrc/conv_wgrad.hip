@@ -156,11 +156,6 @@ __device__ __forceinline__ void wgrad1x1_body(const WgradParams& p, const int bi
   const int ctiles = p.ctiles, ntiles = (p.N + 127) / 128;
   int t_idx, chunk;
   if (!xcd_group(bid, ctiles * ntiles, p.S, t_idx, chunk)) return;     // grid padded to 8 chunks
-  if (p.prio) {
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    if (p.prio == 1 && (hw & 1)) __builtin_amdgcn_s_setprio(3);
-  }
   // the C / 32 sub-tiles are dealt evenly over the channel tiles (10 over 3 tiles: 3 + 3 + 4, not 4 + 4 + 2)
   const int nsub = (p.C + 31) / 32, ct = t_idx % ctiles;
   const int sub0 = ct * nsub / ctiles;
@@ -304,8 +299,8 @@ __device__ __forceinline__ void wgrad1x1_body(const WgradParams& p, const int bi
 #pragma unroll 1
       for (int st = 0; st < steps; ++st) {
         const int buf = st & 1;
-#ifdef DDL_PHASE_PROBE      // knock-outs (p.prio 2: no staging in the loop, 3: no MFMAs) - timing experiments, wrong results
-        const bool ko_stage = p.prio == 2, ko_mfma = p.prio == 3;
+#ifdef DDL_PHASE_PROBE      // knock-outs (DDL_WGRAD_KO=2: no staging in the loop, 3: no MFMAs) - timing experiments, wrong results
+        const bool ko_stage = p.ko == 2, ko_mfma = p.ko == 3;
 #else
         constexpr bool ko_stage = false, ko_mfma = false;
 #endif
@@ -484,8 +479,8 @@ __device__ __forceinline__ void wgrad3x3_body(const WgradParams& p, const int bi
   __syncthreads();
   for (int st = 0; st < steps; ++st) {
     const int buf = st & 1;
-#ifdef DDL_PHASE_PROBE      // knock-outs (p.prio 2: no staging in the loop, 3: no MFMAs) - timing experiments, wrong results
-    const bool ko_stage = p.prio == 2, ko_mfma = p.prio == 3;
+#ifdef DDL_PHASE_PROBE      // knock-outs (DDL_WGRAD_KO=2: no staging in the loop, 3: no MFMAs) - timing experiments, wrong results
+    const bool ko_stage = p.ko == 2, ko_mfma = p.ko == 3;
 #else
     constexpr bool ko_stage = false, ko_mfma = false;
 #endif
@@ -598,9 +593,9 @@ __global__ void __launch_bounds__(256, 2) wgrad_group_kernel(const WgradGroupPar
   p.a.bytes1 = 0;
   p.M = g.M; p.C = en.C; p.N = g.N; p.H = g.H; p.W = g.W; p.taps = TAPS;
   p.rows_per_wg = g.rows_per_wg; p.slabs = en.slabs; p.S = g.S; p.sub = 4; p.ctiles = en.ctiles;
-  p.bf16 = g.bf16; p.prio = 0;
+  p.bf16 = g.bf16;
 #ifdef DDL_PHASE_PROBE
-  p.dbg = nullptr;
+  p.dbg = nullptr; p.ko = 0;
 #endif
   const int bid = (int)blockIdx.x - en.block0;
   if (TAPS == 1) wgrad1x1_body<4, true, 1, BF>(p, bid, smem);
